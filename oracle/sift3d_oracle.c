@@ -222,7 +222,7 @@ int orc_fir_axis(const float *src, float *dst, int nx, int ny, int nz, int axis,
     /* restructured path: per-tap constant (offset, frac) -- valid when
      * (float)g - d*uf is exact, i.e. uf = 2^-k and g < 2^(23-k) */
     const int fast = mode == 1 && is_dyadic(uf, &shift) && shift <= 12 &&
-                     n_glob < (1 << (23 - shift)) && axis != 0;
+                     n_glob < (1 << (23 - shift)) && hw < 1024 && axis != 0;
     int *toff = NULL;
     float *tw0 = NULL, *tw1 = NULL;
 
@@ -232,7 +232,7 @@ int orc_fir_axis(const float *src, float *dst, int nx, int ny, int nz, int axis,
         tw0 = (float *)malloc(sizeof(float) * width);
         tw1 = (float *)malloc(sizeof(float) * width);
         for (d = -hw; d <= hw; d++) {
-            const int g0 = 1 << 20; /* any exact, non-negative reference index */
+            const int g0 = 1 << 10; /* reference index: g0 +- hw*uf exact in float */
             const float c = (float)g0 - d * uf;
             const int lo = (int)c;
             const float frac = c - (float)lo;

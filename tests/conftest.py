@@ -1,0 +1,20 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "refprobe: needs oracle/_ref (build container only)")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import sift3d_oracle as so
+    so.lib()
+    return so
