@@ -1,0 +1,248 @@
+/* sift3d_amd.h -- MI355X-side C ABI underneath the drop-in API (include/sift3d/).
+ *
+ * Two groups of entry points, all `extern "C"`, plain pointers and sizes:
+ *
+ *  sift3d_amd_*  extensions of the reference API that only make sense with a
+ *                device: hand the detector a volume that is already resident in
+ *                HBM, query stage timings, generate synthetic volumes.
+ *  sift3d_hip_*  the stage kernels themselves, operating on DEVICE pointers and a
+ *                HIP stream.  The C host code of the drop-in library calls these;
+ *                so does the Z-slab multi-GPU driver (sift3d_amd/sharded.py), which
+ *                is why every stage takes local-slab geometry (global length,
+ *                offset of the local buffer, plane range to produce).
+ *
+ * Each stage cites the reference function (file:line under /root/reference/sift3d/)
+ * whose results it reproduces.  Volumes are float32, x fastest:
+ * index = x + nx*(y + ny*z) (reference: imutil.c:520-533).
+ */
+#ifndef SIFT3D_AMD_H
+#define SIFT3D_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "sift3d/imtypes.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIFT3D_AMD_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------ */
+/* Extensions of the drop-in API                                            */
+/* ------------------------------------------------------------------------ */
+
+/* As sift3d_detect_keypoints (reference: sift.c:1217-1249) for a single-channel
+ * nx*ny*nz float32 volume that already lives in device memory (`d_volume`), with
+ * voxel spacing (ux,uy,uz).  The volume is not modified. */
+SIFT3D_AMD_API int
+sift3d_amd_detect_keypoints_device(sift3d_detector *det, const float *d_volume,
+                                   int nx, int ny, int nz, double ux, double uy,
+                                   double uz, sift3d_keypoint_store *store);
+
+/* Voxel spacing of an image made by sift3d_make_image (the reference sets units
+ * only through its NIfTI reader, nifti.c:52-167). */
+SIFT3D_AMD_API int
+sift3d_amd_image_set_units(sift3d_image *im, double ux, double uy, double uz);
+
+/* Wall-clock seconds of the stages of the last detect/describe on `det`:
+ * [0] upload+scale  [1] Gaussian pyramid  [2] DoG  [3] extrema  [4] orientation
+ * [5] describe  [6] pyramid kernels only, device time from HIP events
+ * [7] whole detect, device time  [8] whole describe, device time.  */
+#define SIFT3D_AMD_NUM_TIMINGS 9
+SIFT3D_AMD_API const double *
+sift3d_amd_timings(const sift3d_detector *det);
+
+/* Number of DoG extrema before orientation filtering in the last detect. */
+SIFT3D_AMD_API int
+sift3d_amd_num_candidates(const sift3d_detector *det);
+
+/* Copy level (o, s) of the Gaussian (which=0) or DoG (which=1) pyramid, or the
+ * scaled input (which=2), of the last detect to host memory.  dims receives
+ * nx,ny,nz.  `out` may be NULL to query dims only. */
+SIFT3D_AMD_API int
+sift3d_amd_copy_level(const sift3d_detector *det, int which, int o, int s,
+                      float *out, int *dims);
+
+/* Raw views of the stores (the reference keeps these private; the parity tests
+ * need R, sd, strength without the "%f" CSV rounding of *_save). */
+SIFT3D_AMD_API int
+sift3d_amd_keypoint_store_size(const sift3d_keypoint_store *);
+SIFT3D_AMD_API int
+sift3d_amd_keypoint_store_get(const sift3d_keypoint_store *, int i, int *o, int *s,
+                              double *xyz_sd /*4*/, float *strength, float *R /*9*/);
+SIFT3D_AMD_API int
+sift3d_amd_keypoint_store_set(sift3d_keypoint_store *, int n, const int *os /*2n*/,
+                              const double *xyz_sd /*4n*/, const float *strength,
+                              const float *R /*9n*/);
+SIFT3D_AMD_API int
+sift3d_amd_descriptor_store_size(const sift3d_descriptor_store *);
+
+/* 1 when a usable HIP device is present. */
+SIFT3D_AMD_API int sift3d_amd_device_available(void);
+SIFT3D_AMD_API const char *sift3d_amd_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* Device plumbing (so that the C host code needs no HIP headers)           */
+/* ------------------------------------------------------------------------ */
+SIFT3D_AMD_API int sift3d_hip_device_count(void);
+SIFT3D_AMD_API int sift3d_hip_set_device(int dev);
+SIFT3D_AMD_API void *sift3d_hip_malloc(size_t bytes);
+SIFT3D_AMD_API void sift3d_hip_free(void *d_ptr);
+SIFT3D_AMD_API void *sift3d_hip_host_alloc(size_t bytes); /* pinned */
+SIFT3D_AMD_API void sift3d_hip_host_free(void *h_ptr);
+SIFT3D_AMD_API int sift3d_hip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+SIFT3D_AMD_API int sift3d_hip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+SIFT3D_AMD_API int sift3d_hip_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
+SIFT3D_AMD_API int sift3d_hip_memset(void *d_dst, int byte, size_t bytes, void *stream);
+SIFT3D_AMD_API void *sift3d_hip_stream_create(void);
+SIFT3D_AMD_API void sift3d_hip_stream_destroy(void *stream);
+SIFT3D_AMD_API int sift3d_hip_stream_sync(void *stream);
+/* HIP events, for device-side stage timing */
+SIFT3D_AMD_API void *sift3d_hip_event_create(void);
+SIFT3D_AMD_API void sift3d_hip_event_destroy(void *ev);
+SIFT3D_AMD_API int sift3d_hip_event_record(void *ev, void *stream);
+SIFT3D_AMD_API double sift3d_hip_event_elapsed_ms(void *ev_start, void *ev_stop); /* syncs on stop */
+
+/* ------------------------------------------------------------------------ */
+/* Stage kernels                                                            */
+/* ------------------------------------------------------------------------ */
+
+/* im_max_abs (imutil.c:681-695): *d_max = max(*d_max, max|src[i]|).  d_max is a
+ * device float the caller zeroes first (max is order independent => exact). */
+SIFT3D_AMD_API int
+sift3d_hip_absmax(const float *d_src, size_t n, float *d_max, void *stream);
+
+/* im_scale (imutil.c:699-713): dst = src / *d_max, a plain copy when *d_max == 0. */
+SIFT3D_AMD_API int
+sift3d_hip_scale(const float *d_src, float *d_dst, size_t n, const float *d_max,
+                 void *stream);
+
+#define SIFT3D_HIP_MAX_TAPS 65
+
+/* One 1-D pass of convolve_sep_gen (imutil.c:742-861) along `axis`, applied directly
+ * on the x-fastest volume (no im_permute copies, imutil.c:907-958).
+ *
+ *  unit_factor = (float)(unit / units[axis])             (imutil.c:754-755)
+ *  z_lo, z_hi    local plane range [z_lo, z_hi) of outputs to produce
+ *  n_glob, off   axis 2 only: the buffers hold planes [off, off + nz) of a global
+ *                axis of n_glob planes; mirror rules use global coordinates and
+ *                interior samples must be present locally (halo).  Unsharded:
+ *                n_glob = nz, off = 0.
+ *  variant       0 = pick the fastest specialised kernel, 1 = force the literal
+ *                one-thread-per-voxel kernel (used by tests to A/B the fast paths) */
+typedef struct {
+    const float *src;
+    float *dst;
+    int nx, ny, nz;
+    int axis;
+    int width;
+    const float *taps; /* host pointer */
+    float unit_factor;
+    int n_glob, off;
+    int z_lo, z_hi;
+    int variant;
+} sift3d_hip_fir_args;
+
+SIFT3D_AMD_API int
+sift3d_hip_fir(const sift3d_hip_fir_args *args, void *stream);
+
+/* im_subtract (imutil.c:719-739) fused with the dogmax scan of detect_extrema
+ * (sift.c:821-826): dst = a - b and *d_absmax = max(*d_absmax, max|dst|).
+ * d_absmax may be NULL. */
+SIFT3D_AMD_API int
+sift3d_hip_subtract_absmax(const float *d_a, const float *d_b, float *d_dst, size_t n,
+                           float *d_absmax, void *stream);
+
+/* im_downsample_2x (imutil.c:591-617): dst(x,y,z) = src(2x,2y,2z) for the mx*my*mz
+ * output box; src rows are nx long, planes nx*ny. */
+SIFT3D_AMD_API int
+sift3d_hip_downsample2(const float *d_src, int nx, int ny, float *d_dst, int mx, int my,
+                       int mz, void *stream);
+
+/* One DoG level for the extrema search */
+typedef struct {
+    const float *prev, *cur, *next; /* D[o,s-1], D[o,s], D[o,s+1]: same local dims */
+    const float *d_absmax;          /* device float: max|D[o,s]| over the GLOBAL level */
+    int z_lo, z_hi;                 /* local planes to test; planes z-1 and z+1 must exist */
+    int tag;                        /* copied into every record (level id) */
+} sift3d_hip_extrema_level;
+
+typedef struct {
+    uint32_t idx;   /* local linear index x + nx*(y + ny*z) */
+    int32_t tag;
+    float val;      /* |D| at the voxel = keypoint strength (sift.c:864) */
+} sift3d_hip_cand;
+
+/* detect_extrema (sift.c:735-871, default 8-neighbour build) for `nlevels` levels of
+ * one octave (all nx*ny*nz).  Records are APPENDED to d_out starting at *d_count in
+ * the reference's scan order (level, z, y, x); *d_count (device uint32) is advanced
+ * by the number found, even past `cap` (records beyond cap are dropped, the caller
+ * compares the final count with cap).  d_work: scratch of
+ * sift3d_hip_extrema_work_bytes() bytes. */
+SIFT3D_AMD_API size_t
+sift3d_hip_extrema_work_bytes(int nx, int ny, int nz, int nlevels);
+SIFT3D_AMD_API int
+sift3d_hip_extrema(const sift3d_hip_extrema_level *levels, int nlevels, int nx, int ny,
+                   int nz, double peak_thresh, sift3d_hip_cand *d_out, uint32_t cap,
+                   uint32_t *d_count, void *d_work, size_t work_bytes, void *stream);
+
+/* Geometry of one Gaussian level, as the window kernels see it (a table of these
+ * lives in device memory, indexed by the `tag`/`level` of a record). */
+typedef struct {
+    const float *data;
+    int nx, ny, nz;  /* local buffer dims */
+    int z_off;       /* global z of local plane 0 */
+    int nz_glob;     /* global number of planes (window clipping, sift.c:97-99) */
+    float ux, uy, uz;/* (float) units of the level (sift.c:88-90) */
+    int octave;
+    double sd;       /* level scale (sift.c:860) */
+} sift3d_hip_level;
+
+/* assign_eig_ori + assign_orientation_thresh (sift.c:926-1102) for n candidates.
+ * d_R: 9 floats per candidate (row-major), d_keep: 1 = kept, 0 = rejected. */
+SIFT3D_AMD_API int
+sift3d_hip_orient(const sift3d_hip_level *d_levels, const sift3d_hip_cand *d_cand,
+                  uint32_t n, double corner_thresh, float *d_R, int32_t *d_keep,
+                  void *stream);
+
+typedef struct {
+    float R[9];
+    float cx, cy, cz; /* (float) keypoint voxel coordinates in its level, global z */
+    int32_t level;
+    double sd;
+} sift3d_hip_kp;
+
+/* extract_descrip (sift.c:1442-1536): 768 floats per keypoint into d_hist. */
+SIFT3D_AMD_API int
+sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d_kp,
+                    uint32_t n, float *d_hist, void *stream);
+
+/* Icosahedron face table for the descriptor kernel (init_geometry, sift.c:148-259;
+ * per-face constants of cart2bary, sift.c:276-297).  20 records of
+ * {v0[3], e1[3], e2[3], t[3], q[3], e2.q, idx[3] (as float)} = 19 floats each. */
+#define SIFT3D_HIP_FACE_FLOATS 19
+SIFT3D_AMD_API int
+sift3d_hip_set_mesh(const float *faces /* 20 * SIFT3D_HIP_FACE_FLOATS */);
+
+/* Order-independent synthetic volume (sift3d_amd/csrc/synth.c) generated on the
+ * device: planes [z_off, z_off + nz) of a volume with nx*ny rows. */
+SIFT3D_AMD_API int
+sift3d_hip_synth_lattice(float *d_dst, int nx, int ny, int nz, int z_off, uint64_t seed,
+                         void *stream);
+
+/* Host evaluations of the device math (tests compare them with libm / LAPACK). */
+SIFT3D_AMD_API void sift3d_amd_host_expf(const float *in, float *out, size_t n);
+SIFT3D_AMD_API void sift3d_amd_host_eigen3(const double *A9, double *Q9, double *L3);
+/* The same two routines evaluated ON the device (one thread per element). */
+SIFT3D_AMD_API int sift3d_hip_test_expf(const float *d_in, float *d_out, size_t n, void *stream);
+SIFT3D_AMD_API int sift3d_hip_test_eigen3(const double *d_A9, double *d_Q9, double *d_L3,
+                                          size_t n, void *stream);
+
+SIFT3D_AMD_API const char *sift3d_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

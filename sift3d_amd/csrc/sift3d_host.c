@@ -1,0 +1,1294 @@
+/* sift3d_host.c -- C host side of the MI355X drop-in for fatimp/SIFT3D v2.0.
+ *
+ * Implements the 27 public symbols of the reference library (the headers under include/sift3d/,
+ * reference: sift3d/sift.h, sift3d/imutil.h) with the reference's object semantics,
+ * parameter checks and error behaviour, and drives the detect / describe hot path
+ * through the device-level C ABI of include/sift3d_amd.h (sift3d_kernels.hip).  There
+ * is NO CPU fallback: without a HIP device the two hot entry points fail loudly.
+ *
+ * What lives where:
+ *   host   object lifetimes, parameter validation, octave/level geometry, the Gaussian
+ *          filter bank (computed with the host libm exactly as the reference does,
+ *          imutil.c:1267-1343), candidate -> keypoint compaction (with the reference's
+ *          stale-strength quirk), stores, converters, CSV writers
+ *   HBM    the scaled input, both pyramids, scratch volumes, candidate / keypoint /
+ *          descriptor records -- resident across sift3d_detect_keypoints and
+ *          sift3d_extract_descriptors like the reference's retained pyramids
+ *          (sift.c:1544-1549)
+ *
+ * Citations are file:line under /root/reference/sift3d/.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <zlib.h>
+
+#include "../../include/sift3d/imutil.h"
+#include "../../include/sift3d/sift.h"
+#include "../../include/sift3d_amd.h"
+
+#define ERR(...) fprintf(stderr, __VA_ARGS__) /* SIFT3D_ERR, immacros.h:31 */
+
+#define NFACES 20
+#define NVERT 12
+#define DESC_NUMEL 768
+#define SLAB_LEN 500 /* SIFT3D_SLAB_LEN, immacros.h:199-201 */
+
+/* sift.c:31-35, :48 */
+static const double peak_thresh_default = 0.1;
+static const int num_kp_levels_default = 3;
+static const double corner_thresh_default = 0.4;
+static const double sigma_n_default = 1.15;
+static const double sigma0_default = 1.6;
+static const double golden_ratio = 1.6180339887;
+
+/* ------------------------------------------------------------------------ */
+/* object layouts (private; the API only exposes opaque handles)             */
+/* ------------------------------------------------------------------------ */
+struct _sift3d_image {
+    float *data;
+    size_t size;
+    int nx, ny, nz, nc;
+    double ux, uy, uz;
+};
+
+struct _sift3d_mat_rm {
+    void *data;
+    size_t size; /* bytes */
+    int num_cols, num_rows;
+    sift3d_mat_type type;
+};
+
+typedef struct {
+    float R[9];
+    double xd, yd, zd, sd;
+    int o, s;
+    float strength;
+} keypoint_t;
+
+struct _sift3d_keypoint_store {
+    keypoint_t *buf;
+    size_t num, cap;
+    int nx, ny, nz;
+};
+
+typedef struct {
+    float hist[DESC_NUMEL];
+    double xd, yd, zd, sd;
+} descriptor_t;
+
+struct _sift3d_descriptor_store {
+    descriptor_t *buf;
+    size_t num;
+    int nx, ny, nz;
+};
+
+typedef struct {
+    double sigma;
+    int width;
+    float *taps;
+} filter_t;
+
+struct _sift3d_detector {
+    /* parameters (sift.c:499-565) */
+    double peak_thresh, corner_thresh, sigma_n, sigma0;
+    int num_kp_levels;
+    /* image geometry */
+    int have_im;
+    int nx, ny, nz;
+    double units[3];       /* units of the current image              */
+    double alloc_units[3]; /* units of the image that sized the pyramid */
+    /* pyramid geometry */
+    int num_octaves, ngl, ndl;
+    int (*odims)[3];       /* per octave */
+    filter_t *filt;        /* [0] first blur, [1..ngl-1] octave filters */
+    int nfilt;
+    /* device state */
+    void *stream;
+    void *ev[8];
+    float *d_im, *d_tmp_a, *d_tmp_b, *d_in;
+    size_t in_cap;
+    float **d_g, **d_d;    /* [num_octaves*ngl], [num_octaves*ndl] */
+    float *d_scalars;      /* [0] input max, [1] count (as u32), [8 + o*ndl + s] dogmax */
+    sift3d_hip_level *h_levels, *d_levels;
+    sift3d_hip_cand *d_cand, *h_cand;
+    uint32_t cand_cap;
+    float *d_R, *h_R;
+    int32_t *d_keep, *h_keep;
+    void *d_work;
+    size_t work_bytes;
+    sift3d_hip_kp *d_kp, *h_kp;
+    float *d_hist, *h_hist;
+    uint32_t kp_cap;
+    int have_pyramid;
+    int ncand;
+    double t[SIFT3D_AMD_NUM_TIMINGS];
+};
+
+static int g_mesh_ready = 0;
+
+static double now_s(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec + 1e-9 * t.tv_nsec;
+}
+
+static const char k_version[] = "sift3d_amd 0.1 (gfx950)";
+const char *sift3d_amd_version(void) { return k_version; }
+
+/* ------------------------------------------------------------------------ */
+/* images (imutil.c:1639-1674)                                               */
+/* ------------------------------------------------------------------------ */
+sift3d_image *sift3d_make_image(const int nx, const int ny, const int nz, const int nc)
+{
+    sift3d_image *im;
+    /* im_resize, imutil.c:560-575 */
+    if (nx <= 0 || ny <= 0 || nz <= 0) {
+        ERR("im_resize: invalid dimension: %d x %d x %d \n", nx, ny, nz);
+        return NULL;
+    }
+    if (nc < 1) {
+        ERR("im_resize: invalid number of channels: %d \n", nc);
+        return NULL;
+    }
+    im = (sift3d_image *)calloc(1, sizeof(*im));
+    if (!im)
+        return NULL;
+    im->nx = nx; im->ny = ny; im->nz = nz; im->nc = nc;
+    im->ux = im->uy = im->uz = 1;               /* init_im, imutil.c:1249-1251 */
+    im->size = (size_t)nx * ny * nz * nc;
+    im->data = (float *)calloc(im->size, sizeof(float)); /* im_zero, imutil.c:507 */
+    if (!im->data) {
+        free(im);
+        return NULL;
+    }
+    return im;
+}
+
+void sift3d_free_image(sift3d_image *im)
+{
+    if (!im)
+        return;
+    free(im->data);
+    free(im);
+}
+
+static const char *file_ext(const char *path)
+{
+    /* get_file_ext, imutil.c:303-315 */
+    const char *name = strrchr(path, '/');
+    const char *dot;
+    name = name ? name : path;
+    dot = strrchr(name, '.');
+    return (!dot || dot == name) ? "" : dot + 1;
+}
+
+sift3d_image *sift3d_read_image(const char *path)
+{
+    const char *ext = file_ext(path);
+    if (!strcmp(ext, "img") || !strcmp(ext, "gz") || !strcmp(ext, "nii")) {
+        /* nifti.c:16-31: the wrapper is not part of this build */
+        ERR("sift3d_read_image: this build has no NIFTI support (nifticlib is not "
+            "available); fill an image made with sift3d_make_image() instead \n");
+    } else {
+        ERR("im_read: unrecognized file extension from file %s \n", path); /* imutil.c:366 */
+    }
+    return NULL;
+}
+
+float *sift3d_image_data(const sift3d_image *im) { return im->data; }
+
+int sift3d_amd_image_set_units(sift3d_image *im, double ux, double uy, double uz)
+{
+    if (!im || !(ux > 0) || !(uy > 0) || !(uz > 0))
+        return SIFT3D_FAILURE;
+    im->ux = ux; im->uy = uy; im->uz = uz;
+    return SIFT3D_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------ */
+/* matrices (imutil.c:226-279, 1676-1710)                                    */
+/* ------------------------------------------------------------------------ */
+static int mat_resize(sift3d_mat_rm *m, int rows, int cols, sift3d_mat_type type)
+{
+    const size_t el = type == SIFT3D_DOUBLE ? sizeof(double)
+                                            : type == SIFT3D_FLOAT ? sizeof(float) : sizeof(int);
+    const size_t total = el * (size_t)rows * (size_t)cols;
+    m->num_rows = rows;
+    m->num_cols = cols;
+    m->type = type;
+    if (total == m->size)
+        return SIFT3D_SUCCESS;
+    if (total == 0) {
+        free(m->data);
+        m->data = NULL;
+        m->size = 0;
+        return SIFT3D_SUCCESS;
+    }
+    {
+        void *p = realloc(m->data, total);
+        if (!p) {
+            free(m->data);
+            m->data = NULL;
+            m->size = 0;
+            return SIFT3D_FAILURE;
+        }
+        m->data = p;
+        m->size = total;
+    }
+    return SIFT3D_SUCCESS;
+}
+
+sift3d_mat_rm *sift3d_make_mat_rm()
+{
+    sift3d_mat_rm *m = (sift3d_mat_rm *)calloc(1, sizeof(*m));
+    if (m)
+        m->type = SIFT3D_FLOAT; /* imutil.c:1678 */
+    return m;
+}
+
+void sift3d_free_mat_rm(sift3d_mat_rm *m)
+{
+    if (!m)
+        return;
+    free(m->data);
+    free(m);
+}
+
+void *sift3d_mat_rm_data(sift3d_mat_rm *m) { return m->data; }
+
+void sift3d_mat_rm_dimensions(const sift3d_mat_rm *m, int *num_cols, int *num_rows)
+{
+    if (num_cols)
+        *num_cols = m->num_cols;
+    if (num_rows)
+        *num_rows = m->num_rows;
+}
+
+sift3d_mat_type sift3d_mat_rm_type(const sift3d_mat_rm *m) { return m->type; }
+
+/* write_Mat_rm, imutil.c:405-479: "%f" / "%d", ',' between columns, '\n' after a row,
+ * gzip when the extension is "gz" */
+static int mat_write(const char *path, const sift3d_mat_rm *m)
+{
+    const int compress = strcmp(file_ext(path), "gz") == 0;
+    FILE *f = NULL;
+    gzFile gz = NULL;
+    int i, j, ok = 1;
+    char buf[64];
+    if (compress) {
+        if (!(gz = gzopen(path, "w")))
+            return SIFT3D_FAILURE;
+    } else if (!(f = fopen(path, "w"))) {
+        return SIFT3D_FAILURE;
+    }
+    for (i = 0; i < m->num_rows && ok; i++)
+        for (j = 0; j < m->num_cols; j++) {
+            const size_t k = (size_t)j + (size_t)i * m->num_cols;
+            const char delim = j < m->num_cols - 1 ? ',' : '\n';
+            int len;
+            switch (m->type) {
+            case SIFT3D_DOUBLE: len = snprintf(buf, sizeof(buf), "%f", ((double *)m->data)[k]); break;
+            case SIFT3D_FLOAT: len = snprintf(buf, sizeof(buf), "%f", ((float *)m->data)[k]); break;
+            default: len = snprintf(buf, sizeof(buf), "%d", ((int *)m->data)[k]); break;
+            }
+            if (len >= (int)sizeof(buf) - 1) { /* huge magnitudes: fall back to direct printf */
+                if (compress)
+                    gzprintf(gz, "%f", m->type == SIFT3D_DOUBLE ? ((double *)m->data)[k]
+                                                                  : (double)((float *)m->data)[k]);
+                else
+                    fprintf(f, "%f", m->type == SIFT3D_DOUBLE ? ((double *)m->data)[k]
+                                                                : (double)((float *)m->data)[k]);
+                len = 0;
+            }
+            buf[len] = delim;
+            if (compress) {
+                if (gzwrite(gz, buf, (unsigned)len + 1) != len + 1)
+                    ok = 0;
+            } else if (fwrite(buf, 1, (size_t)len + 1, f) != (size_t)len + 1) {
+                ok = 0;
+            }
+        }
+    if (compress) {
+        if (gzclose(gz) != Z_OK)
+            ok = 0;
+    } else {
+        if (ferror(f))
+            ok = 0;
+        fclose(f);
+    }
+    return ok ? SIFT3D_SUCCESS : SIFT3D_FAILURE;
+}
+
+/* ------------------------------------------------------------------------ */
+/* stores (sift.c:329-423, 1861-1900)                                        */
+/* ------------------------------------------------------------------------ */
+sift3d_keypoint_store *sift3d_make_keypoint_store()
+{
+    return (sift3d_keypoint_store *)calloc(1, sizeof(sift3d_keypoint_store));
+}
+
+void sift3d_free_keypoint_store(sift3d_keypoint_store *kp)
+{
+    if (!kp)
+        return;
+    free(kp->buf);
+    free(kp);
+}
+
+/* resize_Keypoint_store: capacity moves in slabs of 500 records (immacros.h:202-222) */
+static int kp_store_resize(sift3d_keypoint_store *kp, size_t num)
+{
+    const size_t cap = ((num + SLAB_LEN - 1) / SLAB_LEN) * SLAB_LEN;
+    if (cap != kp->cap) {
+        if (cap == 0) {
+            free(kp->buf);
+            kp->buf = NULL;
+        } else {
+            keypoint_t *p = (keypoint_t *)realloc(kp->buf, cap * sizeof(keypoint_t));
+            if (!p) {
+                free(kp->buf);
+                kp->buf = NULL;
+                kp->cap = kp->num = 0;
+                return SIFT3D_FAILURE;
+            }
+            kp->buf = p;
+        }
+        kp->cap = cap;
+    }
+    kp->num = num;
+    return SIFT3D_SUCCESS;
+}
+
+sift3d_descriptor_store *sift3d_make_descriptor_store()
+{
+    return (sift3d_descriptor_store *)calloc(1, sizeof(sift3d_descriptor_store));
+}
+
+void sift3d_free_descriptor_store(sift3d_descriptor_store *d)
+{
+    if (!d)
+        return;
+    free(d->buf);
+    free(d);
+}
+
+/* keypoint_strength_cmp never returns 0 (sift.c:1832-1837, quirk Q7) */
+static int strength_cmp(const void *a, const void *b)
+{
+    return (((const keypoint_t *)a)->strength < ((const keypoint_t *)b)->strength) ? 1 : -1;
+}
+
+void sift3d_keypoint_store_sort_by_strength(sift3d_keypoint_store *const store, int limit)
+{
+    if (!store->num)
+        return;
+    qsort(store->buf, store->num, sizeof(keypoint_t), strength_cmp);
+    if (store->num > (size_t)limit && limit != 0)  /* sift.c:1897-1899 */
+        kp_store_resize(store, (size_t)limit);
+}
+
+int sift3d_keypoint_store_to_mat_rm(const sift3d_keypoint_store *const kp, sift3d_mat_rm *const mat)
+{
+    const int num = (int)kp->num;
+    int i;
+    if (mat_resize(mat, num, 3, SIFT3D_DOUBLE))
+        return SIFT3D_FAILURE;
+    for (i = 0; i < num; i++) {
+        const keypoint_t *k = kp->buf + i;
+        const double f = ldexp(1.0, k->o);        /* sift.c:1663 */
+        double *row = (double *)mat->data + 3 * (size_t)i;
+        row[0] = f * k->xd;
+        row[1] = f * k->yd;
+        row[2] = f * k->zd;
+    }
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_descriptor_store_to_mat_rm(const sift3d_descriptor_store *const store,
+                                      sift3d_mat_rm *const mat)
+{
+    const int rows = (int)store->num, cols = 3 + DESC_NUMEL;
+    int i;
+    if (rows < 1) {                                /* sift.c:1691-1695 */
+        printf("SIFT3D_Descriptor_store_to_Mat_rm: invalid number of descriptors: %d \n", rows);
+        return SIFT3D_FAILURE;
+    }
+    if (mat_resize(mat, rows, cols, SIFT3D_FLOAT))
+        return SIFT3D_FAILURE;
+    for (i = 0; i < rows; i++) {
+        const descriptor_t *d = store->buf + i;
+        float *row = (float *)mat->data + (size_t)cols * i;
+        row[0] = (float)d->xd;
+        row[1] = (float)d->yd;
+        row[2] = (float)d->zd;
+        memcpy(row + 3, d->hist, sizeof(float) * DESC_NUMEL); /* col = 3 + 12*cell + bin */
+    }
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_keypoint_store_save(const char *path, const sift3d_keypoint_store *const kp)
+{
+    /* columns: strength, x, y, z, o, sd, R00..R22 (sift.c:1746-1789) */
+    sift3d_mat_rm m;
+    const int rows = (int)kp->num, cols = 15;
+    int i, j, ret;
+    memset(&m, 0, sizeof(m));
+    if (mat_resize(&m, rows, cols, SIFT3D_DOUBLE))
+        return SIFT3D_FAILURE;
+    for (i = 0; i < rows; i++) {
+        const keypoint_t *k = kp->buf + i;
+        double *row = (double *)m.data + (size_t)cols * i;
+        row[0] = k->strength;
+        row[1] = k->xd;
+        row[2] = k->yd;
+        row[3] = k->zd;
+        row[4] = k->o;
+        row[5] = k->sd;
+        for (j = 0; j < 9; j++)
+            row[6 + j] = (double)k->R[j];
+    }
+    ret = mat_write(path, &m);
+    free(m.data);
+    return ret;
+}
+
+int sift3d_descriptor_store_save(const char *path, const sift3d_descriptor_store *const desc)
+{
+    sift3d_mat_rm m;
+    int ret;
+    memset(&m, 0, sizeof(m));
+    m.type = SIFT3D_FLOAT;
+    if (sift3d_descriptor_store_to_mat_rm(desc, &m)) {
+        free(m.data);
+        return SIFT3D_FAILURE;
+    }
+    ret = mat_write(path, &m);
+    free(m.data);
+    return ret;
+}
+
+int sift3d_amd_keypoint_store_size(const sift3d_keypoint_store *kp) { return (int)kp->num; }
+int sift3d_amd_descriptor_store_size(const sift3d_descriptor_store *d) { return (int)d->num; }
+
+int sift3d_amd_keypoint_store_get(const sift3d_keypoint_store *kp, int i, int *o, int *s,
+                                  double *xyz_sd, float *strength, float *R)
+{
+    const keypoint_t *k;
+    if (i < 0 || (size_t)i >= kp->num)
+        return SIFT3D_FAILURE;
+    k = kp->buf + i;
+    if (o) *o = k->o;
+    if (s) *s = k->s;
+    if (xyz_sd) { xyz_sd[0] = k->xd; xyz_sd[1] = k->yd; xyz_sd[2] = k->zd; xyz_sd[3] = k->sd; }
+    if (strength) *strength = k->strength;
+    if (R) memcpy(R, k->R, sizeof(k->R));
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_amd_keypoint_store_set(sift3d_keypoint_store *kp, int n, const int *os,
+                                  const double *xyz_sd, const float *strength, const float *R)
+{
+    int i;
+    if (n < 0 || kp_store_resize(kp, (size_t)n))
+        return SIFT3D_FAILURE;
+    for (i = 0; i < n; i++) {
+        keypoint_t *k = kp->buf + i;
+        k->o = os[2 * i];
+        k->s = os[2 * i + 1];
+        k->xd = xyz_sd[4 * i];
+        k->yd = xyz_sd[4 * i + 1];
+        k->zd = xyz_sd[4 * i + 2];
+        k->sd = xyz_sd[4 * i + 3];
+        k->strength = strength ? strength[i] : 0.0f;
+        memcpy(k->R, R + 9 * i, sizeof(k->R));
+    }
+    return SIFT3D_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------ */
+/* icosahedron (init_geometry, sift.c:148-259) -> device face table          */
+/* ------------------------------------------------------------------------ */
+static int upload_mesh(void)
+{
+    const float g = golden_ratio;
+    const float vert[NVERT][3] = {
+        { 0, 1, g }, { 0, -1, g }, { 0, 1, -g }, { 0, -1, -g }, { 1, g, 0 }, { -1, g, 0 },
+        { 1, -g, 0 }, { -1, -g, 0 }, { g, 0, 1 }, { -g, 0, 1 }, { g, 0, -1 }, { -g, 0, -1 } };
+    static const int faces[NFACES][3] = {
+        { 0, 1, 8 }, { 0, 8, 4 }, { 0, 4, 5 }, { 0, 5, 9 }, { 0, 9, 1 }, { 1, 6, 8 },
+        { 8, 6, 10 }, { 8, 10, 4 }, { 4, 10, 2 }, { 4, 2, 5 }, { 5, 2, 11 }, { 5, 11, 9 },
+        { 9, 11, 7 }, { 9, 7, 1 }, { 1, 7, 6 }, { 3, 6, 7 }, { 3, 7, 11 }, { 3, 11, 2 },
+        { 3, 2, 10 }, { 3, 10, 6 } };
+    float rec[NFACES * SIFT3D_HIP_FACE_FLOATS];
+    int i, j, k;
+    if (g_mesh_ready)
+        return SIFT3D_SUCCESS;
+    for (i = 0; i < NFACES; i++) {
+        float v[3][3], a[3], b[3], n[3];
+        float *r = rec + i * SIFT3D_HIP_FACE_FLOATS;
+        for (j = 0; j < 3; j++) {
+            float mag;
+            for (k = 0; k < 3; k++)
+                v[j][k] = vert[faces[i][j]][k];
+            mag = sqrtf(v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2]);
+            /* SIFT3D_CVEC_SCALE(v, 1.0f / mag) expands to x * 1.0f / mag (sift.c:228) */
+            for (k = 0; k < 3; k++)
+                v[j][k] = v[j][k] * 1.0f / mag;
+        }
+        for (k = 0; k < 3; k++) {
+            a[k] = v[2][k] - v[1][k];
+            b[k] = v[1][k] - v[0][k];
+        }
+        n[0] = a[1] * b[2] - a[2] * b[1];
+        n[1] = a[2] * b[0] - a[0] * b[2];
+        n[2] = a[0] * b[1] - a[1] * b[0];
+        if (n[0] * v[0][0] + n[1] * v[0][1] + n[2] * v[0][2] < 0)
+            for (k = 0; k < 3; k++) { /* swap vertices 0,1 -- idx[] is left alone (Q1) */
+                const float t = v[0][k];
+                v[0][k] = v[1][k];
+                v[1][k] = t;
+            }
+        /* per-face constants of cart2bary (sift.c:276-297) */
+        for (k = 0; k < 3; k++) {
+            r[0 + k] = v[0][k];
+            r[3 + k] = v[1][k] - v[0][k];     /* e1 */
+            r[6 + k] = v[2][k] - v[0][k];     /* e2 */
+            r[9 + k] = v[0][k] * -1.0f;       /* t  */
+        }
+        r[12] = r[10] * r[5] - r[11] * r[4];  /* q = t x e1 */
+        r[13] = r[11] * r[3] - r[9] * r[5];
+        r[14] = r[9] * r[4] - r[10] * r[3];
+        r[15] = r[6] * r[12] + r[7] * r[13] + r[8] * r[14]; /* e2 . q */
+        for (k = 0; k < 3; k++)
+            r[16 + k] = (float)faces[i][k];
+    }
+    if (sift3d_hip_set_mesh(rec))
+        return SIFT3D_FAILURE;
+    g_mesh_ready = 1;
+    return SIFT3D_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------ */
+/* detector: parameters, geometry, filter bank                               */
+/* ------------------------------------------------------------------------ */
+static double level_scale(const sift3d_detector *d, int o, int s)
+{
+    return d->sigma0 * pow(2.0, o + (double)s / d->num_kp_levels); /* imutil.c:1578-1579 */
+}
+
+static void free_filters(sift3d_detector *d)
+{
+    int i;
+    for (i = 0; i < d->nfilt; i++)
+        free(d->filt[i].taps);
+    free(d->filt);
+    d->filt = NULL;
+    d->nfilt = 0;
+}
+
+/* init_Gauss_filter, imutil.c:1267-1319 */
+static int gauss_filter(filter_t *f, double sigma)
+{
+    const int hw = sigma > 0 ? ((int)ceil(sigma * 3.0) > 1 ? (int)ceil(sigma * 3.0) : 1) : 1;
+    const int width = 2 * hw + 1;
+    float acc = 0;
+    int i;
+    f->sigma = sigma;
+    f->width = width;
+    f->taps = (float *)malloc(sizeof(float) * width);
+    if (!f->taps)
+        return SIFT3D_FAILURE;
+    for (i = 0; i < width; i++) {
+        double x = (double)i - hw;
+        x /= sigma + DBL_EPSILON;
+        f->taps[i] = (float)exp(-0.5 * x * x);
+        acc += f->taps[i];
+    }
+    for (i = 0; i < width; i++)
+        f->taps[i] /= acc;
+    return SIFT3D_SUCCESS;
+}
+
+/* make_gss, imutil.c:1360-1409 */
+static int build_filters(sift3d_detector *d)
+{
+    const int nf = d->ngl;
+    int i;
+    free_filters(d);
+    d->filt = (filter_t *)calloc((size_t)nf, sizeof(filter_t));
+    if (!d->filt)
+        return SIFT3D_FAILURE;
+    d->nfilt = nf;
+    for (i = 0; i < nf; i++) {
+        const double s_cur = i == 0 ? d->sigma_n : level_scale(d, 0, i - 2);
+        const double s_next = level_scale(d, 0, i - 1);
+        if (s_cur > s_next) {                      /* imutil.c:1328-1332 */
+            ERR("init_Gauss_incremental_filter: s_cur (%f) > s_next (%f) \n", s_cur, s_next);
+            return SIFT3D_FAILURE;
+        }
+        if (gauss_filter(&d->filt[i], sqrt(s_next * s_next - s_cur * s_cur)))
+            return SIFT3D_FAILURE;
+        if (d->filt[i].width > SIFT3D_HIP_MAX_TAPS) {
+            ERR("sift3d_amd: a %d-tap Gaussian exceeds the device kernels' limit of %d taps \n",
+                d->filt[i].width, SIFT3D_HIP_MAX_TAPS);
+            return SIFT3D_FAILURE;
+        }
+    }
+    return SIFT3D_SUCCESS;
+}
+
+static void free_device_pyramid(sift3d_detector *d)
+{
+    int i;
+    if (d->d_g)
+        for (i = 0; i < d->num_octaves * d->ngl; i++)
+            sift3d_hip_free(d->d_g[i]);
+    if (d->d_d)
+        for (i = 0; i < d->num_octaves * d->ndl; i++)
+            sift3d_hip_free(d->d_d[i]);
+    free(d->d_g);
+    free(d->d_d);
+    d->d_g = d->d_d = NULL;
+    sift3d_hip_free(d->d_im);
+    sift3d_hip_free(d->d_tmp_a);
+    sift3d_hip_free(d->d_tmp_b);
+    sift3d_hip_free(d->d_scalars);
+    sift3d_hip_free(d->d_levels);
+    sift3d_hip_free(d->d_work);
+    d->d_im = d->d_tmp_a = d->d_tmp_b = d->d_scalars = NULL;
+    d->d_levels = NULL;
+    d->d_work = NULL;
+    d->work_bytes = 0;
+    free(d->h_levels);
+    d->h_levels = NULL;
+    free(d->odims);
+    d->odims = NULL;
+    d->num_octaves = 0;
+    d->have_pyramid = 0;
+}
+
+static void fill_level_table(sift3d_detector *d)
+{
+    int o, s, k;
+    for (o = 0; o < d->num_octaves; o++)
+        for (s = 0; s < d->ngl; s++) {
+            sift3d_hip_level *L = &d->h_levels[o * d->ngl + s];
+            /* octave 0 carries the units of the current image (apply_Sep_FIR_filter
+             * copies them from its source, imutil.c:1145); deeper octaves keep what
+             * resize_Pyramid gave them (imutil.c:1533,1545-1548) */
+            const double *u = o == 0 ? d->units : d->alloc_units;
+            double lu[3];
+            for (k = 0; k < 3; k++)
+                lu[k] = o == 0 ? u[k] : u[k] * ldexp(1.0, o);
+            L->data = d->d_g[o * d->ngl + s];
+            L->nx = d->odims[o][0];
+            L->ny = d->odims[o][1];
+            L->nz = d->odims[o][2];
+            L->z_off = 0;
+            L->nz_glob = d->odims[o][2];
+            L->ux = (float)lu[0];
+            L->uy = (float)lu[1];
+            L->uz = (float)lu[2];
+            L->octave = o;
+            L->sd = level_scale(d, o, s - 1);
+        }
+}
+
+/* resize_SIFT3D (sift.c:427-475) + resize_Pyramid (imutil.c:1464-1554) */
+static int resize_detector(sift3d_detector *d)
+{
+    const int ngl = d->num_kp_levels + 3, ndl = d->num_kp_levels + 2;
+    int mn, last_octave, o, s, dims[3];
+    size_t n0, work = 0;
+
+    free_device_pyramid(d);
+    d->ngl = ngl;
+    d->ndl = ndl;
+    if (!d->have_im)
+        return SIFT3D_SUCCESS;
+
+    mn = d->nx < d->ny ? d->nx : d->ny;
+    mn = mn < d->nz ? mn : d->nz;
+    last_octave = (int)log2((double)mn) - 3;         /* sift.c:442-444 */
+    if (last_octave < 0) {
+        ERR("resize_SIFT3D: input image is too small: must have at least 8 voxels in each "
+            "dimension \n");
+        return SIFT3D_FAILURE;
+    }
+    if (ngl < 2) {                                   /* make_gss, imutil.c:1372-1376 */
+        ERR("make_gss: pyr has only %d levels, must have at least 2", ngl);
+        return SIFT3D_FAILURE;
+    }
+    if (level_scale(d, 0, -1) < d->sigma_n) {        /* imutil.c:1582-1588 */
+        ERR("set_scales_Pyramid: sigma_n too large for these settings. Max allowed: %f \n",
+            level_scale(d, 0, -1) - DBL_EPSILON);
+        return SIFT3D_FAILURE;
+    }
+    d->num_octaves = last_octave + 1;
+    memcpy(d->alloc_units, d->units, sizeof(d->units));
+    d->odims = (int(*)[3])calloc((size_t)d->num_octaves, sizeof(int[3]));
+    d->d_g = (float **)calloc((size_t)d->num_octaves * ngl, sizeof(float *));
+    d->d_d = (float **)calloc((size_t)d->num_octaves * ndl, sizeof(float *));
+    d->h_levels = (sift3d_hip_level *)calloc((size_t)d->num_octaves * ngl, sizeof(sift3d_hip_level));
+    if (!d->odims || !d->d_g || !d->d_d || !d->h_levels)
+        return SIFT3D_FAILURE;
+    dims[0] = d->nx; dims[1] = d->ny; dims[2] = d->nz;
+    for (o = 0; o < d->num_octaves; o++) {
+        const size_t n = (size_t)dims[0] * dims[1] * dims[2];
+        const size_t w = sift3d_hip_extrema_work_bytes(dims[0], dims[1], dims[2], ndl - 2);
+        memcpy(d->odims[o], dims, sizeof(dims));
+        for (s = 0; s < ngl; s++)
+            if (!(d->d_g[o * ngl + s] = (float *)sift3d_hip_malloc(n * sizeof(float))))
+                return SIFT3D_FAILURE;
+        for (s = 0; s < ndl; s++)
+            if (!(d->d_d[o * ndl + s] = (float *)sift3d_hip_malloc(n * sizeof(float))))
+                return SIFT3D_FAILURE;
+        work = w > work ? w : work;
+        for (s = 0; s < 3; s++)
+            dims[s] /= 2;                            /* imutil.c:1545-1547 */
+    }
+    n0 = (size_t)d->nx * d->ny * d->nz;
+    d->d_im = (float *)sift3d_hip_malloc(n0 * sizeof(float));
+    d->d_tmp_a = (float *)sift3d_hip_malloc(n0 * sizeof(float));
+    d->d_tmp_b = (float *)sift3d_hip_malloc(n0 * sizeof(float));
+    d->d_scalars = (float *)sift3d_hip_malloc(sizeof(float) * (8 + (size_t)d->num_octaves * ndl));
+    d->d_levels = (sift3d_hip_level *)sift3d_hip_malloc(sizeof(sift3d_hip_level) *
+                                                        (size_t)d->num_octaves * ngl);
+    d->d_work = sift3d_hip_malloc(work);
+    d->work_bytes = work;
+    if (!d->d_im || !d->d_tmp_a || !d->d_tmp_b || !d->d_scalars || !d->d_levels || !d->d_work)
+        return SIFT3D_FAILURE;
+    return build_filters(d);
+}
+
+int sift3d_detector_set_peak_thresh(sift3d_detector *const d, const double v)
+{
+    if (v <= 0.0 || v > 1) {                         /* sift.c:501-505 */
+        ERR("sift3d_detector peak_thresh must be in the interval (0, 1]. Provided: %f \n", v);
+        return SIFT3D_FAILURE;
+    }
+    d->peak_thresh = v;
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_detector_set_corner_thresh(sift3d_detector *const d, const double v)
+{
+    if (v < 0.0 || v > 1.0) {                        /* sift.c:515-519 */
+        ERR("sift3d_detector corner_thresh must be in the interval [0, 1]. Provided: %f \n", v);
+        return SIFT3D_FAILURE;
+    }
+    d->corner_thresh = v;
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_detector_set_num_kp_levels(sift3d_detector *const d, const unsigned int v)
+{
+    d->num_kp_levels = (int)v;                       /* sift.c:527-533 */
+    return resize_detector(d);
+}
+
+/* set_scales_SIFT3D, sift.c:478-496 */
+static int set_scales(sift3d_detector *d, double sigma0, double sigma_n)
+{
+    const double old0 = d->sigma0, oldn = d->sigma_n;
+    d->sigma0 = sigma0;
+    d->sigma_n = sigma_n;
+    if (!d->num_octaves)
+        return SIFT3D_SUCCESS;
+    if (level_scale(d, 0, -1) < sigma_n) {           /* imutil.c:1582-1588 */
+        ERR("set_scales_Pyramid: sigma_n too large for these settings. Max allowed: %f \n",
+            level_scale(d, 0, -1) - DBL_EPSILON);
+        d->sigma0 = old0;
+        d->sigma_n = oldn;
+        return SIFT3D_FAILURE;
+    }
+    d->have_pyramid = 0;
+    return build_filters(d);
+}
+
+int sift3d_detector_set_sigma_n(sift3d_detector *const d, const double v)
+{
+    if (v < 0.0) {                                   /* sift.c:542-546 */
+        ERR("sift3d_detector sigma_n must be nonnegative. Provided: %f \n", v);
+        return SIFT3D_FAILURE;
+    }
+    return set_scales(d, d->sigma0, v);
+}
+
+int sift3d_detector_set_sigma0(sift3d_detector *const d, const double v)
+{
+    if (v < 0.0) {                                   /* sift.c:558-562 */
+        ERR("sift3d_detector sigma0 must be nonnegative. Provided: %f \n", v);
+        return SIFT3D_FAILURE;
+    }
+    return set_scales(d, v, d->sigma_n);
+}
+
+sift3d_detector *sift3d_make_detector()
+{
+    sift3d_detector *d = (sift3d_detector *)calloc(1, sizeof(*d));
+    if (!d)
+        return NULL;
+    d->peak_thresh = peak_thresh_default;
+    d->corner_thresh = corner_thresh_default;
+    d->sigma_n = sigma_n_default;
+    d->sigma0 = sigma0_default;
+    d->num_kp_levels = num_kp_levels_default;
+    d->ngl = d->num_kp_levels + 3;
+    d->ndl = d->num_kp_levels + 2;
+    return d;
+}
+
+void sift3d_free_detector(sift3d_detector *d)
+{
+    int i;
+    if (!d)
+        return;
+    if (d->stream)
+        sift3d_hip_stream_sync(d->stream);
+    free_device_pyramid(d);
+    free_filters(d);
+    sift3d_hip_free(d->d_in);
+    sift3d_hip_free(d->d_cand);
+    sift3d_hip_free(d->d_R);
+    sift3d_hip_free(d->d_keep);
+    sift3d_hip_free(d->d_kp);
+    sift3d_hip_free(d->d_hist);
+    sift3d_hip_host_free(d->h_cand);
+    sift3d_hip_host_free(d->h_R);
+    sift3d_hip_host_free(d->h_keep);
+    sift3d_hip_host_free(d->h_kp);
+    sift3d_hip_host_free(d->h_hist);
+    for (i = 0; i < 8; i++)
+        sift3d_hip_event_destroy(d->ev[i]);
+    sift3d_hip_stream_destroy(d->stream);
+    free(d);
+}
+
+const double *sift3d_amd_timings(const sift3d_detector *d) { return d->t; }
+int sift3d_amd_num_candidates(const sift3d_detector *d) { return d->ncand; }
+
+/* ------------------------------------------------------------------------ */
+/* the hot path                                                              */
+/* ------------------------------------------------------------------------ */
+static int ensure_device(sift3d_detector *d)
+{
+    int i;
+    if (d->stream)
+        return SIFT3D_SUCCESS;
+    if (!sift3d_amd_device_available()) {
+        ERR("sift3d_amd: no HIP device is available; this library has no CPU path \n");
+        return SIFT3D_FAILURE;
+    }
+    if (!(d->stream = sift3d_hip_stream_create()))
+        return SIFT3D_FAILURE;
+    for (i = 0; i < 8; i++)
+        if (!(d->ev[i] = sift3d_hip_event_create()))
+            return SIFT3D_FAILURE;
+    return upload_mesh();
+}
+
+static int ensure_cand_capacity(sift3d_detector *d, uint32_t cap)
+{
+    if (cap <= d->cand_cap)
+        return SIFT3D_SUCCESS;
+    sift3d_hip_free(d->d_cand);
+    sift3d_hip_free(d->d_R);
+    sift3d_hip_free(d->d_keep);
+    sift3d_hip_host_free(d->h_cand);
+    sift3d_hip_host_free(d->h_R);
+    sift3d_hip_host_free(d->h_keep);
+    d->cand_cap = 0;
+    d->d_cand = (sift3d_hip_cand *)sift3d_hip_malloc(sizeof(sift3d_hip_cand) * (size_t)cap);
+    d->d_R = (float *)sift3d_hip_malloc(sizeof(float) * 9 * (size_t)cap);
+    d->d_keep = (int32_t *)sift3d_hip_malloc(sizeof(int32_t) * (size_t)cap);
+    d->h_cand = (sift3d_hip_cand *)sift3d_hip_host_alloc(sizeof(sift3d_hip_cand) * (size_t)cap);
+    d->h_R = (float *)sift3d_hip_host_alloc(sizeof(float) * 9 * (size_t)cap);
+    d->h_keep = (int32_t *)sift3d_hip_host_alloc(sizeof(int32_t) * (size_t)cap);
+    if (!d->d_cand || !d->d_R || !d->d_keep || !d->h_cand || !d->h_R || !d->h_keep)
+        return SIFT3D_FAILURE;
+    d->cand_cap = cap;
+    return SIFT3D_SUCCESS;
+}
+
+/* apply_Sep_FIR_filter (imutil.c:1127-1206) on the device: x, y, z passes, the two
+ * intermediates in scratch volumes, no permute copies */
+static int blur_level(sift3d_detector *d, const float *src, float *dst, const int *dims,
+                      const double *lu, const filter_t *f)
+{
+    const float *in = src;
+    float *outs[3];
+    int ax;
+    outs[0] = d->d_tmp_a;
+    outs[1] = d->d_tmp_b;
+    outs[2] = dst;
+    for (ax = 0; ax < 3; ax++) {
+        sift3d_hip_fir_args a;
+        memset(&a, 0, sizeof(a));
+        a.src = in;
+        a.dst = outs[ax];
+        a.nx = dims[0]; a.ny = dims[1]; a.nz = dims[2];
+        a.axis = ax;
+        a.width = f->width;
+        a.taps = f->taps;
+        a.unit_factor = (float)(1.0 / lu[ax]);     /* unit = 1.0: sift.c:675, imutil.c:754-755 */
+        a.n_glob = dims[2];
+        a.off = 0;
+        a.z_lo = 0;
+        a.z_hi = dims[2];
+        if (sift3d_hip_fir(&a, d->stream))
+            return SIFT3D_FAILURE;
+        in = outs[ax];
+    }
+    return SIFT3D_SUCCESS;
+}
+
+static void level_units(const sift3d_detector *d, int o, double *lu)
+{
+    int k;
+    for (k = 0; k < 3; k++)
+        lu[k] = o == 0 ? d->units[k] : d->alloc_units[k] * ldexp(1.0, o);
+}
+
+/* device part of sift3d_detect_keypoints (sift.c:1217-1249) */
+static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int ny, int nz,
+                            double ux, double uy, double uz, sift3d_keypoint_store *kp)
+{
+    const size_t n0 = (size_t)nx * ny * nz;
+    const int dims_changed = !d->have_im || d->nx != nx || d->ny != ny || d->nz != nz ||
+                             !d->num_octaves;
+    const double t_start = now_s();
+    uint32_t count = 0;
+    int o, s, i, j, attempt;
+
+    /* set_im_SIFT3D, sift.c:629-659 */
+    d->have_im = 1;
+    d->nx = nx; d->ny = ny; d->nz = nz;
+    d->units[0] = ux; d->units[1] = uy; d->units[2] = uz;
+    d->have_pyramid = 0;
+    if (dims_changed && resize_detector(d)) {
+        d->have_im = 0;
+        return SIFT3D_FAILURE;
+    }
+    fill_level_table(d);
+    if (sift3d_hip_memcpy_h2d(d->d_levels, d->h_levels,
+                              sizeof(sift3d_hip_level) * (size_t)d->num_octaves * d->ngl, d->stream))
+        return SIFT3D_FAILURE;
+
+    sift3d_hip_event_record(d->ev[0], d->stream);
+    if (sift3d_hip_memset(d->d_scalars, 0, sizeof(float) * (8 + (size_t)d->num_octaves * d->ndl),
+                          d->stream) ||
+        sift3d_hip_absmax(d_vol, n0, d->d_scalars, d->stream) ||
+        sift3d_hip_scale(d_vol, d->d_im, n0, d->d_scalars, d->stream))
+        return SIFT3D_FAILURE;
+
+    /* build_gpyr, sift.c:662-711 */
+    sift3d_hip_event_record(d->ev[1], d->stream);
+    {
+        double lu[3];
+        level_units(d, 0, lu);
+        if (blur_level(d, d->d_im, d->d_g[0], d->odims[0], lu, &d->filt[0]))
+            return SIFT3D_FAILURE;
+    }
+    for (o = 0; o < d->num_octaves; o++) {
+        double lu[3];
+        level_units(d, o, lu);
+        for (s = 1; s < d->ngl; s++)
+            if (blur_level(d, d->d_g[o * d->ngl + s - 1], d->d_g[o * d->ngl + s], d->odims[o], lu,
+                           &d->filt[s]))             /* gauss_octave[s], sift.c:689 */
+                return SIFT3D_FAILURE;
+        if (o != d->num_octaves - 1) {
+            /* level max(s_end - 2, first_level), sift.c:696-704 */
+            const int s_end = d->ngl - 2;
+            const int ds = s_end - 2 > -1 ? s_end - 2 : -1;
+            if (sift3d_hip_downsample2(d->d_g[o * d->ngl + ds + 1], d->odims[o][0], d->odims[o][1],
+                                       d->d_g[(o + 1) * d->ngl], d->odims[o + 1][0],
+                                       d->odims[o + 1][1], d->odims[o + 1][2], d->stream))
+                return SIFT3D_FAILURE;
+        }
+    }
+    sift3d_hip_event_record(d->ev[2], d->stream);
+
+    /* build_dog (sift.c:713-732) fused with the dogmax scan (sift.c:821-826) */
+    for (o = 0; o < d->num_octaves; o++) {
+        const size_t n = (size_t)d->odims[o][0] * d->odims[o][1] * d->odims[o][2];
+        for (s = 0; s < d->ndl; s++)
+            if (sift3d_hip_subtract_absmax(d->d_g[o * d->ngl + s], d->d_g[o * d->ngl + s + 1],
+                                           d->d_d[o * d->ndl + s], n,
+                                           d->d_scalars + 8 + o * d->ndl + s, d->stream))
+                return SIFT3D_FAILURE;
+    }
+    sift3d_hip_event_record(d->ev[3], d->stream);
+
+    /* detect_extrema, sift.c:735-871 */
+    if (d->ndl < 3) {
+        printf("detect_extrema: Requires at least 3 levels per octave, provided only %d \n", d->ndl);
+        return SIFT3D_FAILURE;
+    }
+    if (ensure_cand_capacity(d, d->cand_cap ? d->cand_cap : (1u << 18)))
+        return SIFT3D_FAILURE;
+    for (attempt = 0; attempt < 2; attempt++) {
+        if (sift3d_hip_memset(d->d_scalars + 1, 0, sizeof(uint32_t), d->stream))
+            return SIFT3D_FAILURE;
+        for (o = 0; o < d->num_octaves; o++) {
+            sift3d_hip_extrema_level lv[8];
+            const int nl = d->ndl - 2;
+            if (nl > 8) {
+                ERR("sift3d_amd: at most 8 keypoint levels per octave are supported \n");
+                return SIFT3D_FAILURE;
+            }
+            for (s = 0; s < nl; s++) {
+                lv[s].prev = d->d_d[o * d->ndl + s];
+                lv[s].cur = d->d_d[o * d->ndl + s + 1];
+                lv[s].next = d->d_d[o * d->ndl + s + 2];
+                lv[s].d_absmax = d->d_scalars + 8 + o * d->ndl + s + 1;
+                lv[s].z_lo = 1;
+                lv[s].z_hi = d->odims[o][2] - 1;
+                lv[s].tag = o * d->ngl + s + 1;      /* Gaussian level (o, s) of the table */
+            }
+            if (sift3d_hip_extrema(lv, nl, d->odims[o][0], d->odims[o][1], d->odims[o][2],
+                                   d->peak_thresh, d->d_cand, d->cand_cap,
+                                   (uint32_t *)(d->d_scalars + 1), d->d_work, d->work_bytes,
+                                   d->stream))
+                return SIFT3D_FAILURE;
+        }
+        if (sift3d_hip_memcpy_d2h(&count, d->d_scalars + 1, sizeof(count), d->stream) ||
+            sift3d_hip_stream_sync(d->stream))
+            return SIFT3D_FAILURE;
+        if (count <= d->cand_cap)
+            break;
+        if (ensure_cand_capacity(d, count + count / 4 + 1024))
+            return SIFT3D_FAILURE;
+    }
+    sift3d_hip_event_record(d->ev[4], d->stream);
+    d->ncand = (int)count;
+
+    /* assign_orientations, sift.c:1109-1167 */
+    if (count) {
+        if (sift3d_hip_orient(d->d_levels, d->d_cand, count, d->corner_thresh, d->d_R, d->d_keep,
+                              d->stream) ||
+            sift3d_hip_memcpy_d2h(d->h_cand, d->d_cand, sizeof(sift3d_hip_cand) * (size_t)count,
+                                  d->stream) ||
+            sift3d_hip_memcpy_d2h(d->h_R, d->d_R, sizeof(float) * 9 * (size_t)count, d->stream) ||
+            sift3d_hip_memcpy_d2h(d->h_keep, d->d_keep, sizeof(int32_t) * (size_t)count, d->stream))
+            return SIFT3D_FAILURE;
+    }
+    sift3d_hip_event_record(d->ev[5], d->stream);
+    if (sift3d_hip_stream_sync(d->stream))
+        return SIFT3D_FAILURE;
+
+    /* keypoint store: dimensions of the first octave (sift.c:756-759), then the in-place
+     * compaction of assign_orientations.  copy_Keypoint does not copy `strength`
+     * (sift.c:372-384), so slot j keeps the strength of CANDIDATE j (quirk Q2). */
+    kp->nx = d->odims[0][0];
+    kp->ny = d->odims[0][1];
+    kp->nz = d->odims[0][2];
+    for (i = 0, j = 0; i < (int)count; i++)
+        j += d->h_keep[i] != 0;
+    if (kp_store_resize(kp, (size_t)j))
+        return SIFT3D_FAILURE;
+    for (i = 0, j = 0; i < (int)count; i++) {
+        const sift3d_hip_cand *c = d->h_cand + i;
+        const sift3d_hip_level *L = d->h_levels + c->tag;
+        keypoint_t *k;
+        size_t plane;
+        uint32_t rem;
+        if (!d->h_keep[i])
+            continue;
+        k = kp->buf + j;
+        plane = (size_t)L->nx * L->ny;
+        rem = (uint32_t)(c->idx % plane);
+        k->o = c->tag / d->ngl;
+        k->s = c->tag % d->ngl - 1;
+        k->xd = (double)(rem % (uint32_t)L->nx);
+        k->yd = (double)(rem / (uint32_t)L->nx);
+        k->zd = (double)(c->idx / plane);
+        k->sd = L->sd;
+        memcpy(k->R, d->h_R + 9 * (size_t)i, sizeof(k->R));
+        k->strength = d->h_cand[j].val;
+        j++;
+    }
+    d->have_pyramid = 1;
+
+    d->t[0] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[0], d->ev[1]);
+    d->t[1] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[1], d->ev[2]);
+    d->t[2] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[2], d->ev[3]);
+    d->t[3] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[3], d->ev[4]);
+    d->t[4] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[4], d->ev[5]);
+    d->t[6] = d->t[1];
+    d->t[7] = now_s() - t_start;
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_amd_detect_keypoints_device(sift3d_detector *d, const float *d_volume, int nx, int ny,
+                                       int nz, double ux, double uy, double uz,
+                                       sift3d_keypoint_store *store)
+{
+    if (!d || !d_volume || !store || nx < 1 || ny < 1 || nz < 1)
+        return SIFT3D_FAILURE;
+    if (ensure_device(d))
+        return SIFT3D_FAILURE;
+    return detect_on_device(d, d_volume, nx, ny, nz, ux, uy, uz, store);
+}
+
+int sift3d_detect_keypoints(sift3d_detector *const d, const sift3d_image *const im,
+                            sift3d_keypoint_store *const kp)
+{
+    size_t n;
+    if (im->nc != 1) {                                 /* sift.c:1221-1226 */
+        ERR("SIFT3D_detect_keypoints: invalid number of image channels: %d -- only "
+            "single-channel images are supported \n", im->nc);
+        return SIFT3D_FAILURE;
+    }
+    if (!im->data)
+        return SIFT3D_FAILURE;                         /* im_copy_data, imutil.c:653-654 */
+    if (ensure_device(d))
+        return SIFT3D_FAILURE;
+    n = (size_t)im->nx * im->ny * im->nz;
+    if (n > d->in_cap) {
+        sift3d_hip_free(d->d_in);
+        d->in_cap = 0;
+        if (!(d->d_in = (float *)sift3d_hip_malloc(n * sizeof(float))))
+            return SIFT3D_FAILURE;
+        d->in_cap = n;
+    }
+    if (sift3d_hip_memcpy_h2d(d->d_in, im->data, n * sizeof(float), d->stream))
+        return SIFT3D_FAILURE;
+    return detect_on_device(d, d->d_in, im->nx, im->ny, im->nz, im->ux, im->uy, im->uz, kp);
+}
+
+int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_store *const kp,
+                               sift3d_descriptor_store *const desc)
+{
+    const int num = (int)kp->num;
+    const double t_start = now_s();
+    int i;
+
+    /* verify_keys, sift.c:1171-1212 (against the retained image dimensions) */
+    if (num < 1) {
+        ERR("verify_keys: invalid number of keypoints: %d \n", num);
+        return SIFT3D_FAILURE;
+    }
+    for (i = 0; i < num; i++) {
+        const keypoint_t *k = kp->buf + i;
+        const double f = ldexp(1.0, k->o);
+        if (k->xd < 0 || k->yd < 0 || k->zd < 0 || k->xd * f >= (double)d->nx ||
+            k->yd * f >= (double)d->ny || k->zd * f >= (double)d->nz) {
+            ERR("verify_keys: keypoint %d (%f, %f, %f) octave %d exceeds image dimensions "
+                "(%d, %d, %d) \n", i, k->xd, k->yd, k->zd, k->o, d->nx, d->ny, d->nz);
+            return SIFT3D_FAILURE;
+        }
+        if (k->sd <= 0) {
+            ERR("verify_keys: keypoint %d has invalid scale %f \n", i, k->sd);
+            return SIFT3D_FAILURE;
+        }
+    }
+    /* detector_has_gpyr, sift.c:1544-1549, 1623-1628 */
+    if (!d->have_pyramid || !d->num_octaves) {
+        ERR("SIFT3D_extract_descriptors: no Gaussian pyramid is available. Make sure "
+            "SIFT3D_detect_keypoints was called prior to calling this function. \n");
+        return SIFT3D_FAILURE;
+    }
+    for (i = 0; i < num; i++) {
+        const keypoint_t *k = kp->buf + i;
+        if (k->o < 0 || k->o >= d->num_octaves || k->s < -1 || k->s > d->ngl - 2) {
+            ERR("sift3d_amd: keypoint %d refers to pyramid level (%d, %d) which does not exist \n",
+                i, k->o, k->s);
+            return SIFT3D_FAILURE;
+        }
+    }
+    if ((uint32_t)num > d->kp_cap) {
+        const uint32_t cap = (uint32_t)num + (uint32_t)num / 4 + 256;
+        sift3d_hip_free(d->d_kp);
+        sift3d_hip_free(d->d_hist);
+        sift3d_hip_host_free(d->h_kp);
+        sift3d_hip_host_free(d->h_hist);
+        d->kp_cap = 0;
+        d->d_kp = (sift3d_hip_kp *)sift3d_hip_malloc(sizeof(sift3d_hip_kp) * (size_t)cap);
+        d->d_hist = (float *)sift3d_hip_malloc(sizeof(float) * DESC_NUMEL * (size_t)cap);
+        d->h_kp = (sift3d_hip_kp *)sift3d_hip_host_alloc(sizeof(sift3d_hip_kp) * (size_t)cap);
+        d->h_hist = (float *)sift3d_hip_host_alloc(sizeof(float) * DESC_NUMEL * (size_t)cap);
+        if (!d->d_kp || !d->d_hist || !d->h_kp || !d->h_hist)
+            return SIFT3D_FAILURE;
+        d->kp_cap = cap;
+    }
+    for (i = 0; i < num; i++) {
+        const keypoint_t *k = kp->buf + i;
+        sift3d_hip_kp *q = d->h_kp + i;
+        memcpy(q->R, k->R, sizeof(q->R));
+        q->cx = (float)k->xd;                          /* sift.c:1474-1476 */
+        q->cy = (float)k->yd;
+        q->cz = (float)k->zd;
+        q->level = k->o * d->ngl + k->s + 1;
+        q->sd = k->sd;
+    }
+    /* do_extract_descriptors, sift.c:1561-1596 */
+    desc->nx = d->odims[0][0];
+    desc->ny = d->odims[0][1];
+    desc->nz = d->odims[0][2];
+    {
+        descriptor_t *p = (descriptor_t *)realloc(desc->buf, sizeof(descriptor_t) * (size_t)num);
+        if (!p) {
+            free(desc->buf);
+            desc->buf = NULL;
+            desc->num = 0;
+            return SIFT3D_FAILURE;
+        }
+        desc->buf = p;
+        desc->num = (size_t)num;
+    }
+    sift3d_hip_event_record(d->ev[6], d->stream);
+    if (sift3d_hip_memcpy_h2d(d->d_kp, d->h_kp, sizeof(sift3d_hip_kp) * (size_t)num, d->stream) ||
+        sift3d_hip_describe(d->d_levels, d->d_kp, (uint32_t)num, d->d_hist, d->stream) ||
+        sift3d_hip_memcpy_d2h(d->h_hist, d->d_hist, sizeof(float) * DESC_NUMEL * (size_t)num,
+                              d->stream))
+        return SIFT3D_FAILURE;
+    sift3d_hip_event_record(d->ev[7], d->stream);
+    if (sift3d_hip_stream_sync(d->stream))
+        return SIFT3D_FAILURE;
+    for (i = 0; i < num; i++) {
+        const keypoint_t *k = kp->buf + i;
+        descriptor_t *q = desc->buf + i;
+        const double f = ldexp(1.0, k->o);             /* sift.c:1459, 1530-1533 */
+        memcpy(q->hist, d->h_hist + (size_t)DESC_NUMEL * i, sizeof(q->hist));
+        q->xd = k->xd * f;
+        q->yd = k->yd * f;
+        q->zd = k->zd * f;
+        q->sd = k->sd;
+    }
+    d->t[5] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[6], d->ev[7]);
+    d->t[8] = now_s() - t_start;
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_amd_copy_level(const sift3d_detector *d, int which, int o, int s, float *out, int *dims)
+{
+    const float *src;
+    size_t n;
+    if (!d->num_octaves || !d->stream)
+        return SIFT3D_FAILURE;
+    if (which == 2) {
+        o = 0;
+        src = d->d_im;
+    } else {
+        const int nl = which == 0 ? d->ngl : d->ndl;
+        if (o < 0 || o >= d->num_octaves || s < -1 || s > nl - 2)
+            return SIFT3D_FAILURE;
+        src = which == 0 ? d->d_g[o * d->ngl + s + 1] : d->d_d[o * d->ndl + s + 1];
+    }
+    if (dims)
+        memcpy(dims, d->odims[o], sizeof(int) * 3);
+    if (!out)
+        return SIFT3D_SUCCESS;
+    n = (size_t)d->odims[o][0] * d->odims[o][1] * d->odims[o][2];
+    if (sift3d_hip_memcpy_d2h(out, src, n * sizeof(float), d->stream) ||
+        sift3d_hip_stream_sync(d->stream))
+        return SIFT3D_FAILURE;
+    return SIFT3D_SUCCESS;
+}

@@ -1,0 +1,1536 @@
+// sift3d_kernels.hip -- hand-written gfx950 (CDNA4, MI355X) kernels of the SIFT3D
+// detect+describe hot path and their C-ABI launchers (include/sift3d_amd.h).
+//
+// All stages are memory-bound stencils or per-keypoint window reductions: no MFMA.
+// Design rules that matter here (cdna_hip_programming.md / MI355X_MICROARCH.md):
+//   * wave = 64 lanes; coalesced 16 B/lane accesses along the unit-stride x axis
+//   * the three 1-D Gaussian passes never transpose the volume in HBM: the x pass stages
+//     row segments in LDS and slides a register window, the y/z passes sweep along the
+//     strided axis with a register ring so every input is loaded once per thread
+//   * bit-exact float32 results vs the reference CPU path: tap order d = -hw..+hw,
+//     `tap * ((1-frac)*lo + frac*hi)` then `+=`, NO fused multiply-add (the file is
+//     compiled with -ffp-contract=off and carries the pragma below)
+//   * window reductions (orientation tensor, descriptor histogram) accumulate in the
+//     reference's voxel scan order, so sums are bit-identical, not just close
+//
+// Reference citations are file:line under /root/reference/sift3d/.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#pragma clang fp contract(off)
+
+#include "../../include/sift3d_amd.h"
+#include "sift3d_math.h"
+#include "synth.h"
+
+// ---------------------------------------------------------------------------------------
+// error handling / plumbing
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(const char *what, hipError_t e, const char *file, int line)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    fprintf(stderr, "sift3d_amd: %s\n", g_err);
+    return SIFT3D_FAILURE;
+}
+
+#define HIPCHK(call)                                                  \
+    do {                                                              \
+        hipError_t e_ = (call);                                       \
+        if (e_ != hipSuccess)                                         \
+            return fail(#call, e_, __FILE__, __LINE__);               \
+    } while (0)
+
+#define LAUNCH_CHECK() HIPCHK(hipGetLastError())
+
+extern "C" {
+
+const char *sift3d_hip_last_error(void) { return g_err; }
+
+int sift3d_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int sift3d_amd_device_available(void) { return sift3d_hip_device_count() > 0; }
+
+int sift3d_hip_set_device(int dev)
+{
+    HIPCHK(hipSetDevice(dev));
+    return SIFT3D_SUCCESS;
+}
+
+void *sift3d_hip_malloc(size_t bytes)
+{
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 4);
+    if (e != hipSuccess) {
+        fail("hipMalloc", e, __FILE__, __LINE__);
+        return nullptr;
+    }
+    return p;
+}
+
+void sift3d_hip_free(void *p)
+{
+    if (p)
+        (void)hipFree(p);
+}
+
+void *sift3d_hip_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 4, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        fail("hipHostMalloc", e, __FILE__, __LINE__);
+        return nullptr;
+    }
+    return p;
+}
+
+void sift3d_hip_host_free(void *p)
+{
+    if (p)
+        (void)hipHostFree(p);
+}
+
+int sift3d_hip_memcpy_h2d(void *d, const void *h, size_t bytes, void *stream)
+{
+    HIPCHK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_memcpy_d2h(void *h, const void *d, size_t bytes, void *stream)
+{
+    HIPCHK(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_memcpy_d2d(void *d, const void *s, size_t bytes, void *stream)
+{
+    HIPCHK(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_memset(void *d, int byte, size_t bytes, void *stream)
+{
+    HIPCHK(hipMemsetAsync(d, byte, bytes, (hipStream_t)stream));
+    return SIFT3D_SUCCESS;
+}
+
+void *sift3d_hip_stream_create(void)
+{
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        fail("hipStreamCreate", e, __FILE__, __LINE__);
+        return nullptr;
+    }
+    return (void *)s;
+}
+
+void sift3d_hip_stream_destroy(void *s)
+{
+    if (s)
+        (void)hipStreamDestroy((hipStream_t)s);
+}
+
+int sift3d_hip_stream_sync(void *s)
+{
+    HIPCHK(hipStreamSynchronize((hipStream_t)s));
+    return SIFT3D_SUCCESS;
+}
+
+void *sift3d_hip_event_create(void)
+{
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess)
+        return nullptr;
+    return (void *)e;
+}
+
+void sift3d_hip_event_destroy(void *e)
+{
+    if (e)
+        (void)hipEventDestroy((hipEvent_t)e);
+}
+
+int sift3d_hip_event_record(void *e, void *s)
+{
+    HIPCHK(hipEventRecord((hipEvent_t)e, (hipStream_t)s));
+    return SIFT3D_SUCCESS;
+}
+
+double sift3d_hip_event_elapsed_ms(void *a, void *b)
+{
+    float ms = 0.f;
+    if (hipEventSynchronize((hipEvent_t)b) != hipSuccess)
+        return -1.0;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess)
+        return -1.0;
+    return (double)ms;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---------------------------------------------------------------------------------------
+// im_max_abs / im_scale  (imutil.c:681-713)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_absmax(const float *__restrict__ src, size_t n,
+                                                unsigned *__restrict__ out)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthr = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = n >> 2;
+    float m = 0.0f;
+    for (size_t i = tid; i < n4; i += nthr) {
+        const float4 v = ld4(src + 4 * i);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    for (size_t i = 4 * n4 + tid; i < n; i += nthr)
+        m = fmaxf(m, fabsf(src[i]));
+    m = wave_max(m);
+    // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0 && m > 0.0f)
+        atomicMax(out, __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void k_scale(const float *__restrict__ src,
+                                               float *__restrict__ dst, size_t n,
+                                               const float *__restrict__ d_max)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthr = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = n >> 2;
+    const float mx = *d_max;
+    if (mx == 0.0f) { // imutil.c:706-707
+        for (size_t i = tid; i < n4; i += nthr)
+            st4(dst + 4 * i, ld4(src + 4 * i));
+        for (size_t i = 4 * n4 + tid; i < n; i += nthr)
+            dst[i] = src[i];
+        return;
+    }
+    for (size_t i = tid; i < n4; i += nthr) {
+        float4 v = ld4(src + 4 * i);
+        v.x = v.x / mx; // imutil.c:711, IEEE division
+        v.y = v.y / mx;
+        v.z = v.z / mx;
+        v.w = v.w / mx;
+        st4(dst + 4 * i, v);
+    }
+    for (size_t i = 4 * n4 + tid; i < n; i += nthr)
+        dst[i] = src[i] / mx;
+}
+
+// ---------------------------------------------------------------------------------------
+// 1-D interpolating FIR  (convolve_sep_gen, imutil.c:742-861)
+// ---------------------------------------------------------------------------------------
+struct FirTaps {
+    float k[SIFT3D_HIP_MAX_TAPS];
+};
+
+struct FirParams {
+    const float *src;
+    float *dst;
+    int nx, ny, nz;   // local dims
+    int axis;
+    int hw;           // half width
+    float uf;         // unit factor
+    int uhw;          // (int)ceilf(hw*uf), imutil.c:756-757
+    int n_glob, off;  // along the filtered axis
+    int z_lo, z_hi;   // output planes
+    int ts;           // sweep segment length (sweep kernels)
+};
+
+// One output sample, the literal arithmetic of the reference.  `line` points at the
+// LOCAL index 0 of the 1-D line; g is the GLOBAL coordinate of the output.  Samples are
+// clamped into the local buffer for memory safety only (a correct call never needs it,
+// except for the weight-0 `hi` read one past the row -- SURVEY.md A.2).
+__device__ __forceinline__ float fir_literal(const float *__restrict__ line, size_t stride,
+                                             int g, int n_glob, int off, int n_loc,
+                                             const float *__restrict__ taps, int hw,
+                                             float uf, int uhw)
+{
+    const int dim_end = n_glob - 1;                               // :753
+    const bool interior = g >= uhw && g <= n_glob - 2 - uhw;      // :762-763, :829
+    float acc = 0.0f;                                             // im_zero, :777
+    float coord = (float)g;
+    for (int d = -hw; d <= hw; d++) {
+        const float tap = taps[d + hw];
+        const float step = (float)d * uf;                         // :808 / :837
+        float c;
+        if (interior) {
+            coord -= step;                                        // :811
+            c = coord;
+        } else {
+            c = (float)g - step;                                  // :835,:840
+            if ((int)c < 0)                                       // :843
+                c = -c;
+            else if ((int)c >= dim_end)                           // :846
+                c = 2.0f * (float)dim_end - c - 0.1f;             // :847-848
+        }
+        const int lo = (int)c;                                    // trunc, :783
+        const float frac = c - (float)lo;                         // :788
+        const int llo = clampi(lo - off, 0, n_loc - 1);
+        const int lhi = clampi(lo + 1 - off, 0, n_loc - 1);
+        const float a = line[(size_t)llo * stride];
+        const float b = line[(size_t)lhi * stride];
+        acc += tap * ((1.0f - frac) * a + frac * b);              // :791-795
+        if (interior)
+            coord += step;                                        // :817
+    }
+    return acc;
+}
+
+// literal kernel: one thread per output voxel, any axis, any unit factor
+__global__ __launch_bounds__(256) void k_fir_literal(FirParams P, FirTaps T)
+{
+    const size_t plane = (size_t)P.nx * P.ny;
+    const size_t total = plane * (size_t)(P.z_hi - P.z_lo);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total)
+        return;
+    const int z = P.z_lo + (int)(i / plane);
+    const size_t r = i % plane;
+    const int y = (int)(r / P.nx);
+    const int x = (int)(r % P.nx);
+    const size_t idx = (size_t)z * plane + r;
+    const float *line;
+    size_t stride;
+    int p, n_loc, off, n_glob;
+    if (P.axis == 0) {
+        line = P.src + (size_t)z * plane + (size_t)y * P.nx;
+        stride = 1; p = x; n_loc = P.nx; off = 0; n_glob = P.nx;
+    } else if (P.axis == 1) {
+        line = P.src + (size_t)z * plane + x;
+        stride = P.nx; p = y; n_loc = P.ny; off = 0; n_glob = P.ny;
+    } else {
+        line = P.src + r;
+        stride = plane; p = z; n_loc = P.nz; off = P.off; n_glob = P.n_glob;
+    }
+    P.dst[idx] = fir_literal(line, stride, p + off, n_glob, off, n_loc, T.k, P.hw, P.uf, P.uhw);
+}
+
+// ---- x pass, unit factor 1 --------------------------------------------------------------
+// One wave per 512-output row segment.  The segment (+8-float halos) is staged in LDS with
+// coalesced 16-byte loads; each lane then pulls a 24-float window into registers and emits
+// 8 outputs.  With frac == 0 the reference's term tap*((1-0)*lo + 0*hi) equals tap*lo
+// exactly for finite data, so the interior is a plain FIR in the reference's tap order.
+template <int HW>
+__global__ __launch_bounds__(256) void k_fir_x_u1(FirParams P, FirTaps T)
+{
+    constexpr int RX = 8, SEG = 64 * RX, HALO = 8, L = SEG + 2 * HALO;
+    static_assert(HW <= HALO, "halo too small");
+    __shared__ __attribute__((aligned(16))) float lds[4][L];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nrows = P.ny * (P.z_hi - P.z_lo);
+    const int row = blockIdx.y * 4 + wave;
+    const bool active = row < nrows;
+    const int x0 = blockIdx.x * SEG;
+    const int nx = P.nx;
+    const size_t rowoff = active ? ((size_t)(P.z_lo + row / P.ny) * P.ny + (row % P.ny)) * nx : 0;
+    const float *__restrict__ s = P.src + rowoff;
+    float *__restrict__ d = P.dst + rowoff;
+    const bool vec_ok = (nx & 3) == 0 && ((((uintptr_t)P.src | (uintptr_t)P.dst) & 15) == 0);
+
+    if (active) {
+        for (int i = lane; i < L / 4; i += 64) {
+            const int gx = x0 - HALO + 4 * i;
+            float4 v;
+            if (vec_ok && gx >= 0 && gx + 3 < nx) {
+                v = ld4(s + gx);
+            } else {
+                v.x = (gx >= 0 && gx < nx) ? s[gx] : 0.0f;
+                v.y = (gx + 1 >= 0 && gx + 1 < nx) ? s[gx + 1] : 0.0f;
+                v.z = (gx + 2 >= 0 && gx + 2 < nx) ? s[gx + 2] : 0.0f;
+                v.w = (gx + 3 >= 0 && gx + 3 < nx) ? s[gx + 3] : 0.0f;
+            }
+            *reinterpret_cast<float4 *>(&lds[wave][4 * i]) = v;
+        }
+    }
+    __syncthreads();
+    if (!active)
+        return;
+    const int xb = x0 + lane * RX; // first output of this lane
+    if (xb >= nx)
+        return;
+    float w[RX + 2 * HALO];
+#pragma unroll
+    for (int i = 0; i < (RX + 2 * HALO) / 4; i++) {
+        const float4 v = *reinterpret_cast<const float4 *>(&lds[wave][lane * RX + 4 * i]);
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    float o[RX];
+#pragma unroll
+    for (int r = 0; r < RX; r++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int dd = -HW; dd <= HW; dd++)
+            acc += T.k[dd + HW] * w[HALO + r - dd];   // src index x - d
+        o[r] = acc;
+    }
+    // boundary outputs: the literal mirror arithmetic, straight from global memory
+    if (xb < HW || xb + RX - 1 > nx - 2 - HW) {
+#pragma unroll
+        for (int r = 0; r < RX; r++) {
+            const int x = xb + r;
+            if (x < nx && (x < HW || x > nx - 2 - HW))
+                o[r] = fir_literal(s, 1, x, nx, 0, nx, T.k, HW, 1.0f, HW);
+        }
+    }
+    if (vec_ok && xb + RX <= nx) {
+        st4(d + xb, make_float4(o[0], o[1], o[2], o[3]));
+        st4(d + xb + 4, make_float4(o[4], o[5], o[6], o[7]));
+    } else {
+#pragma unroll
+        for (int r = 0; r < RX; r++)
+            if (xb + r < nx)
+                d[xb + r] = o[r];
+    }
+}
+
+// ---- y / z pass, unit factor 1 ----------------------------------------------------------
+// Each thread owns V adjacent x (one 16-byte quad for V=4) and sweeps `ts` outputs along
+// the strided axis, keeping the 2*HW+1 most recent input rows in a register ring: every
+// input is loaded once per thread, loads are coalesced along x, nothing is transposed.
+// Whether an output row is "interior" depends only on the sweep coordinate, which is
+// wave-uniform, so the mirror path costs no divergence.
+template <int V> struct Vec;
+template <> struct Vec<4> {
+    typedef float4 T;
+    static __device__ __forceinline__ T ld(const float *p) { return ld4(p); }
+    static __device__ __forceinline__ void st(float *p, T v) { st4(p, v); }
+    static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ void mac(T &acc, float k, const T &v)
+    {
+        acc.x += k * v.x; acc.y += k * v.y; acc.z += k * v.z; acc.w += k * v.w;
+    }
+};
+template <> struct Vec<1> {
+    typedef float T;
+    static __device__ __forceinline__ T ld(const float *p) { return *p; }
+    static __device__ __forceinline__ void st(float *p, T v) { *p = v; }
+    static __device__ __forceinline__ T zero() { return 0.0f; }
+    static __device__ __forceinline__ void mac(T &acc, float k, const T &v) { acc += k * v; }
+};
+
+struct SweepGeom {
+    int ncols;          // number of V-wide columns
+    int cols_inner;     // columns per contiguous run (row for the y pass, plane for z)
+    size_t outer_stride;// floats between runs (plane for the y pass)
+    int outer_lo;       // first run (z_lo for the y pass)
+    size_t stride;      // floats between consecutive samples along the sweep axis
+    int n_loc;          // local extent of the sweep axis
+    int out_lo, out_hi; // local output range along the sweep axis
+};
+
+template <int HW, int V>
+__global__ __launch_bounds__(256) void k_fir_sweep_u1(FirParams P, SweepGeom G, FirTaps T)
+{
+    typedef typename Vec<V>::T vec;
+    constexpr int W = 2 * HW + 1;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= G.ncols)
+        return;
+    const int p0 = G.out_lo + blockIdx.y * P.ts;
+    const int p1 = min(p0 + P.ts, G.out_hi);
+    const size_t base = (size_t)(G.outer_lo + col / G.cols_inner) * G.outer_stride +
+                        (size_t)(col % G.cols_inner) * V;
+    const float *__restrict__ s = P.src + base;
+    float *__restrict__ d = P.dst + base;
+    const int nl1 = G.n_loc - 1;
+    const int off = P.off, n_glob = P.n_glob;
+
+    vec ring[W];
+#pragma unroll
+    for (int i = 0; i < 2 * HW; i++)
+        ring[i] = Vec<V>::ld(s + (size_t)clampi(p0 - HW + i, 0, nl1) * G.stride);
+
+#pragma unroll 1
+    for (int p = p0; p < p1; p += W) {
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            const int q = p + j;
+            ring[(j + 2 * HW) % W] = Vec<V>::ld(s + (size_t)clampi(q + HW, 0, nl1) * G.stride);
+            if (q < p1) {
+                const int g = q + off;
+                vec acc = Vec<V>::zero();
+                if (g >= HW && g <= n_glob - 2 - HW) {
+#pragma unroll
+                    for (int dd = -HW; dd <= HW; dd++)
+                        Vec<V>::mac(acc, T.k[dd + HW], ring[(j + HW - dd) % W]);
+                } else {
+                    float *a = reinterpret_cast<float *>(&acc);
+#pragma unroll
+                    for (int v = 0; v < V; v++)
+                        a[v] = fir_literal(s + v, G.stride, g, n_glob, off, G.n_loc, T.k, HW,
+                                           1.0f, HW);
+                }
+                Vec<V>::st(d + (size_t)q * G.stride, acc);
+            }
+        }
+    }
+}
+
+// ---- dyadic unit factors (octaves >= 1): per-tap constant (offset, frac) -------------------
+// For uf = 2^-k the sample coordinate g - d*uf is exact in float, so every interior output
+// uses the same per-tap integer offset and interpolation weights (computed on the host with
+// the reference's float expressions).  One thread per V-wide column and output row; the
+// arithmetic per tap is the literal tap*((1-frac)*lo + frac*hi).
+struct DyadTaps {
+    float k[SIFT3D_HIP_MAX_TAPS];
+    float w0[SIFT3D_HIP_MAX_TAPS]; // 1 - frac
+    float w1[SIFT3D_HIP_MAX_TAPS]; // frac
+    int off[SIFT3D_HIP_MAX_TAPS];  // lo - g
+};
+
+template <int V>
+__global__ __launch_bounds__(256) void k_fir_sweep_dyad(FirParams P, SweepGeom G,
+                                                        const DyadTaps *__restrict__ Tp)
+{
+    typedef typename Vec<V>::T vec;
+    __shared__ DyadTaps T;
+    for (int i = threadIdx.x; i < (int)(sizeof(DyadTaps) / 4); i += blockDim.x)
+        reinterpret_cast<int *>(&T)[i] = reinterpret_cast<const int *>(Tp)[i];
+    __syncthreads();
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= G.ncols)
+        return;
+    const int q = G.out_lo + blockIdx.y;
+    const size_t base = (size_t)(G.outer_lo + col / G.cols_inner) * G.outer_stride +
+                        (size_t)(col % G.cols_inner) * V;
+    const float *__restrict__ s = P.src + base;
+    float *__restrict__ d = P.dst + base;
+    const int g = q + P.off;
+    const int nl1 = G.n_loc - 1;
+    const int W = 2 * P.hw + 1;
+    vec acc = Vec<V>::zero();
+    if (g >= P.uhw && g <= P.n_glob - 2 - P.uhw) {
+        for (int t = 0; t < W; t++) {
+            const int lo = clampi(q + T.off[t], 0, nl1);
+            const int hi = clampi(q + T.off[t] + 1, 0, nl1);
+            const vec a = Vec<V>::ld(s + (size_t)lo * G.stride);
+            const vec b = Vec<V>::ld(s + (size_t)hi * G.stride);
+            const float tap = T.k[t], w0 = T.w0[t], w1 = T.w1[t];
+            const float *af = reinterpret_cast<const float *>(&a);
+            const float *bf = reinterpret_cast<const float *>(&b);
+            float *cf = reinterpret_cast<float *>(&acc);
+#pragma unroll
+            for (int v = 0; v < V; v++)
+                cf[v] += tap * (w0 * af[v] + w1 * bf[v]);
+        }
+    } else {
+        float *cf = reinterpret_cast<float *>(&acc);
+#pragma unroll
+        for (int v = 0; v < V; v++)
+            cf[v] = fir_literal(s + v, G.stride, g, P.n_glob, P.off, G.n_loc, T.k, P.hw, P.uf,
+                                P.uhw);
+    }
+    Vec<V>::st(d + (size_t)q * G.stride, acc);
+}
+
+// x pass for dyadic unit factors: one thread per output voxel, taps from LDS
+__global__ __launch_bounds__(256) void k_fir_x_dyad(FirParams P, const DyadTaps *__restrict__ Tp)
+{
+    __shared__ DyadTaps T;
+    for (int i = threadIdx.x; i < (int)(sizeof(DyadTaps) / 4); i += blockDim.x)
+        reinterpret_cast<int *>(&T)[i] = reinterpret_cast<const int *>(Tp)[i];
+    __syncthreads();
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= P.nx)
+        return;
+    const int row = blockIdx.y; // (y, z) pair inside the plane range
+    const size_t rowoff = ((size_t)(P.z_lo + row / P.ny) * P.ny + (row % P.ny)) * P.nx;
+    const float *__restrict__ s = P.src + rowoff;
+    const int nl1 = P.nx - 1;
+    const int W = 2 * P.hw + 1;
+    float acc = 0.0f;
+    if (x >= P.uhw && x <= P.nx - 2 - P.uhw) {
+        for (int t = 0; t < W; t++) {
+            const float a = s[clampi(x + T.off[t], 0, nl1)];
+            const float b = s[clampi(x + T.off[t] + 1, 0, nl1)];
+            acc += T.k[t] * (T.w0[t] * a + T.w1[t] * b);
+        }
+    } else {
+        acc = fir_literal(s, 1, x, P.nx, 0, P.nx, T.k, P.hw, P.uf, P.uhw);
+    }
+    P.dst[rowoff + x] = acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// im_subtract + dogmax  (imutil.c:719-739, sift.c:821-826)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sub_absmax(const float *__restrict__ a,
+                                                    const float *__restrict__ b,
+                                                    float *__restrict__ dst, size_t n,
+                                                    unsigned *__restrict__ out)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthr = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = n >> 2;
+    float m = 0.0f;
+    for (size_t i = tid; i < n4; i += nthr) {
+        const float4 u = ld4(a + 4 * i), v = ld4(b + 4 * i);
+        float4 r;
+        r.x = u.x - v.x; r.y = u.y - v.y; r.z = u.z - v.z; r.w = u.w - v.w;
+        st4(dst + 4 * i, r);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
+    }
+    for (size_t i = 4 * n4 + tid; i < n; i += nthr) {
+        const float r = a[i] - b[i];
+        dst[i] = r;
+        m = fmaxf(m, fabsf(r));
+    }
+    if (out) {
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0 && m > 0.0f)
+            atomicMax(out, __float_as_uint(m));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// im_downsample_2x  (imutil.c:591-617)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_downsample2(const float *__restrict__ src, int nx, int ny,
+                                                     float *__restrict__ dst, int mx, int my,
+                                                     int mz)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    const int z = blockIdx.z;
+    if (x >= mx)
+        return;
+    dst[(size_t)x + (size_t)mx * ((size_t)y + (size_t)my * z)] =
+        src[(size_t)(2 * x) + (size_t)nx * ((size_t)(2 * y) + (size_t)ny * (2 * z))];
+}
+
+// ---------------------------------------------------------------------------------------
+// detect_extrema  (sift.c:735-871): mask -> scan -> emit, output in scan order
+// ---------------------------------------------------------------------------------------
+constexpr int EX_WPB = 32; // 64-voxel words per block (8 per wave)
+
+struct ExLevels {
+    sift3d_hip_extrema_level lv[8];
+};
+
+struct ExGeom {
+    int nx, ny, nz;
+    int wpr;        // words per row = ceil(nx / 64)
+    uint32_t nwords;// nz * ny * wpr
+    uint32_t nblk;  // ceil(nwords / EX_WPB)
+    double peak_thresh;
+};
+
+__global__ __launch_bounds__(256) void k_extrema_mask(ExLevels LV, ExGeom E,
+                                                      unsigned long long *__restrict__ masks,
+                                                      uint32_t *__restrict__ blk_counts)
+{
+    __shared__ uint32_t wc[4];
+    const int level = blockIdx.y;
+    const sift3d_hip_extrema_level L = LV.lv[level];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // thr = (float)(peak_thresh * dogmax), sift.c:829
+    const float thr = (float)(E.peak_thresh * (double)(*L.d_absmax));
+    const size_t ys = E.nx, zs = (size_t)E.nx * E.ny;
+    uint32_t cnt = 0;
+    for (int w = 0; w < EX_WPB / 4; w++) {
+        const uint32_t word = blockIdx.x * EX_WPB + wave * (EX_WPB / 4) + w;
+        if (word >= E.nwords)
+            break; // wave-uniform
+        const uint32_t row = word / E.wpr;
+        const int x = (int)(word % E.wpr) * 64 + lane;
+        const int z = (int)(row / E.ny);
+        const int y = (int)(row % E.ny);
+        bool hit = false;
+        if (z >= L.z_lo && z < L.z_hi && y >= 1 && y <= E.ny - 2 && x >= 1 && x <= E.nx - 2) {
+            const size_t p = (size_t)x + ys * y + zs * z;
+            const float v = L.cur[p];
+            if (v > thr || v < -thr) {                               // sift.c:842
+                const float n0 = L.prev[p], n1 = L.cur[p + 1], n2 = L.cur[p - 1],
+                            n3 = L.cur[p + ys], n4 = L.cur[p - ys], n5 = L.cur[p - zs],
+                            n6 = L.cur[p + zs], n7 = L.next[p];
+                hit = (v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6 &&
+                       v > n7) ||
+                      (v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6 &&
+                       v < n7);                                      // sift.c:844-849
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0)
+            masks[(size_t)level * E.nwords + word] = m;
+        cnt += (uint32_t)__popcll(m);
+    }
+    if (lane == 0)
+        wc[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        blk_counts[(size_t)level * E.nblk + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+// exclusive scan of the block counts (single workgroup), based at *d_count
+__global__ __launch_bounds__(1024) void k_extrema_scan(uint32_t *__restrict__ blk, uint32_t n,
+                                                       uint32_t *__restrict__ d_count)
+{
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    const int t = threadIdx.x;
+    if (t == 0)
+        carry = *d_count;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + t;
+        const uint32_t v = i < n ? blk[i] : 0;
+        part[t] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint32_t add = t >= o ? part[t - o] : 0;
+            __syncthreads();
+            part[t] += add;
+            __syncthreads();
+        }
+        if (i < n)
+            blk[i] = carry + part[t] - v;
+        __syncthreads();
+        if (t == 0)
+            carry += part[1023];
+        __syncthreads();
+    }
+    if (t == 0)
+        *d_count = carry;
+}
+
+__global__ __launch_bounds__(256) void k_extrema_emit(ExLevels LV, ExGeom E,
+                                                      const unsigned long long *__restrict__ masks,
+                                                      const uint32_t *__restrict__ blk_off,
+                                                      sift3d_hip_cand *__restrict__ out,
+                                                      uint32_t cap)
+{
+    __shared__ uint32_t pre[EX_WPB + 1];
+    const int level = blockIdx.y;
+    const sift3d_hip_extrema_level L = LV.lv[level];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t w0 = blockIdx.x * EX_WPB;
+    if (threadIdx.x < EX_WPB) {
+        const uint32_t word = w0 + threadIdx.x;
+        pre[threadIdx.x + 1] =
+            word < E.nwords ? (uint32_t)__popcll(masks[(size_t)level * E.nwords + word]) : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pre[0] = 0;
+        for (int i = 1; i <= EX_WPB; i++)
+            pre[i] += pre[i - 1];
+    }
+    __syncthreads();
+    if (pre[EX_WPB] == 0)
+        return;
+    const uint32_t base = blk_off[(size_t)level * E.nblk + blockIdx.x];
+    const size_t ys = E.nx, zs = (size_t)E.nx * E.ny;
+    for (int w = 0; w < EX_WPB / 4; w++) {
+        const int wi = wave * (EX_WPB / 4) + w;
+        const uint32_t word = w0 + wi;
+        if (word >= E.nwords)
+            break;
+        const unsigned long long m = masks[(size_t)level * E.nwords + word];
+        if (!((m >> lane) & 1ull))
+            continue;
+        const uint32_t pos = base + pre[wi] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos >= cap)
+            continue;
+        const uint32_t row = word / E.wpr;
+        const int x = (int)(word % E.wpr) * 64 + lane;
+        const size_t p = (size_t)x + ys * (row % E.ny) + zs * (row / E.ny);
+        sift3d_hip_cand c;
+        c.idx = (uint32_t)p;
+        c.tag = L.tag;
+        c.val = fabsf(L.cur[p]);                                     // sift.c:864
+        out[pos] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// window geometry shared by orientation and descriptor (IM_LOOP_SPHERE_START, sift.c:86-107)
+// ---------------------------------------------------------------------------------------
+struct Box {
+    int xs, xe, ys, ye, zs, ze; // inclusive, global z
+};
+
+// rad is double in assign_eig_ori (sift.c:936) and float in extract_descrip (sift.c:1454);
+// the macro's expressions are promoted accordingly before floorf/ceilf.
+__device__ __forceinline__ void bounds_d(float c, double rad, float u, int n, int &s, int &e)
+{
+    const float lo = floorf((float)((double)c - rad / (double)u));
+    const float hi = ceilf((float)((double)c + rad / (double)u));
+    s = (int)(lo > 1.0f ? lo : 1.0f);
+    e = (int)(hi < (float)(n - 2) ? hi : (float)(n - 2));
+}
+
+__device__ __forceinline__ void bounds_f(float c, float rad, float u, int n, int &s, int &e)
+{
+    const float lo = floorf(c - rad / u);
+    const float hi = ceilf(c + rad / u);
+    s = (int)(lo > 1.0f ? lo : 1.0f);
+    e = (int)(hi < (float)(n - 2) ? hi : (float)(n - 2));
+}
+
+// IM_GET_GRAD_ISO (sift.c:140-145, immacros.h:105-111); z is a LOCAL plane index
+__device__ __forceinline__ void grad_iso(const sift3d_hip_level &L, int x, int y, int zl, float &gx,
+                                         float &gy, float &gz)
+{
+    const size_t ys = L.nx, zs = (size_t)L.nx * L.ny;
+    const float *p = L.data + (size_t)x + ys * y + zs * zl;
+    gx = 0.5f * (p[1] - *(p - 1));
+    gy = 0.5f * (p[ys] - *(p - ys));
+    gz = 0.5f * (p[zs] - *(p - zs));
+    gx *= 1.0f / L.ux;
+    gy *= 1.0f / L.uy;
+    gz *= 1.0f / L.uz;
+}
+
+// ---------------------------------------------------------------------------------------
+// assign_eig_ori + assign_orientation_thresh  (sift.c:926-1102): one wave per candidate.
+//
+// The window is walked in the reference's scan order (z, y, x) in chunks of 64 voxels.
+// Lanes compute their voxel's nine terms in parallel; the terms are then added in voxel
+// order by nine accumulator lanes (six double structure-tensor sums, three float gradient
+// sums), which makes every sum bit-identical to the serial CPU loop.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restrict__ levels,
+                                               const sift3d_hip_cand *__restrict__ cand, uint32_t n,
+                                               double corner_thresh, float *__restrict__ Rout,
+                                               int32_t *__restrict__ keep)
+{
+    __shared__ double td[6][64];
+    __shared__ float tf[3][64];
+    const uint32_t ci = blockIdx.x;
+    if (ci >= n)
+        return;
+    const int lane = threadIdx.x;
+    const sift3d_hip_cand C = cand[ci];
+    const sift3d_hip_level L = levels[C.tag];
+    const size_t plane = (size_t)L.nx * L.ny;
+    const int kz_loc = (int)(C.idx / plane);
+    const int rem = (int)(C.idx % plane);
+    const int ky = rem / L.nx, kx = rem % L.nx, kz = kz_loc + L.z_off;
+    // vcenter = {key->xd, key->yd, key->zd} as float (sift.c:1124)
+    const float cx = (float)kx, cy = (float)ky, cz = (float)kz;
+    const double sigma = 1.5 * L.sd;            // ori_sig_fctr, sift.c:1125
+    const double rad = sigma * 3.0;             // ori_rad_fctr, sift.c:936
+    const double rad2 = rad * rad;
+    const double sig2 = sigma * sigma;
+    Box B;
+    bounds_d(cx, rad, L.ux, L.nx, B.xs, B.xe);
+    bounds_d(cy, rad, L.uy, L.ny, B.ys, B.ye);
+    bounds_d(cz, rad, L.uz, L.nz_glob, B.zs, B.ze);
+    const int bx = B.xe - B.xs + 1, by = B.ye - B.ys + 1;
+    const int npl = bx > 0 && by > 0 ? bx * by : 0;
+
+    double dacc = 0.0; // lanes 0..5: A00 A01 A02 A11 A12 A22
+    float facc = 0.0f; // lanes 6..8: vd_win x y z
+
+    for (int z = B.zs; z <= B.ze; z++) {
+        const float dz = ((float)z - cz) * L.uz;
+        for (int c0 = 0; c0 < npl; c0 += 64) {
+            const int i = c0 + lane;
+            bool in = false;
+            float gx = 0.f, gy = 0.f, gz = 0.f, w = 0.f;
+            if (i < npl) {
+                const int yy = i / bx, xx = i - yy * bx;
+                const int x = B.xs + xx, y = B.ys + yy;
+                const float dx = ((float)x - cx) * L.ux;          // sift.c:102-104
+                const float dy = ((float)y - cy) * L.uy;
+                const float sq = dx * dx + dy * dy + dz * dz;     // sift.c:105
+                if (!((double)sq > rad2)) {                       // sift.c:106 (double)
+                    in = true;
+                    w = s3d_expf((float)(-0.5 * (double)sq / sig2)); // sift.c:972
+                    grad_iso(L, x, y, z - L.z_off, gx, gy, gz);
+                }
+            }
+            if (__ballot(in) == 0ull)
+                continue; // nothing to add in this chunk (adding exact zeros is a no-op)
+            // sift.c:978-987
+            td[0][lane] = in ? (double)gx * (double)gx * (double)w : 0.0;
+            td[1][lane] = in ? (double)gx * (double)gy * (double)w : 0.0;
+            td[2][lane] = in ? (double)gx * (double)gz * (double)w : 0.0;
+            td[3][lane] = in ? (double)gy * (double)gy * (double)w : 0.0;
+            td[4][lane] = in ? (double)gy * (double)gz * (double)w : 0.0;
+            td[5][lane] = in ? (double)gz * (double)gz * (double)w : 0.0;
+            tf[0][lane] = in ? gx * w : 0.0f;
+            tf[1][lane] = in ? gy * w : 0.0f;
+            tf[2][lane] = in ? gz * w : 0.0f;
+            __syncthreads();
+            if (lane < 6) {
+#pragma unroll 8
+                for (int j = 0; j < 64; j++)
+                    dacc += td[lane][j];
+            } else if (lane < 9) {
+#pragma unroll 8
+                for (int j = 0; j < 64; j++)
+                    facc += tf[lane - 6][j];
+            }
+            __syncthreads();
+        }
+    }
+    // gather the nine sums on every lane (uniform epilogue, no divergence)
+    double A[9];
+    A[0] = __shfl(dacc, 0, 64); A[1] = __shfl(dacc, 1, 64); A[2] = __shfl(dacc, 2, 64);
+    A[4] = __shfl(dacc, 3, 64); A[5] = __shfl(dacc, 4, 64); A[8] = __shfl(dacc, 5, 64);
+    A[3] = A[1]; A[6] = A[2]; A[7] = A[5];
+    const float wx = __shfl(facc, 6, 64), wy = __shfl(facc, 7, 64), wz = __shfl(facc, 8, 64);
+
+    int kept = 1;
+    float R[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (wx * wx + wy * wy + wz * wz < (float)1E-10) {             // sift.c:997
+        kept = 0;
+    } else {
+        double Q[9], Lm[3];
+        s3d_eigen3(A, Q, Lm);                                     // eigen_Mat_rm, imutil.c:984
+        if (fabs(Lm[0] / Lm[1]) > 0.90 || fabs(Lm[1] / Lm[2]) > 0.90) { // sift.c:1011-1015
+            kept = 0;
+        } else {
+            double corner = 1.7976931348623157e308;               // DBL_MAX, sift.c:1018
+            float v[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int e = 2 - i;
+                float vx = (float)Q[0 * 3 + e], vy = (float)Q[1 * 3 + e], vz = (float)Q[2 * 3 + e];
+                const double d = (double)(wx * vx + wy * vy + wz * vz);           // sift.c:1029
+                const double cos_ang =
+                    d / (double)(sqrtf(vx * vx + vy * vy + vz * vz) *
+                                 sqrtf(wx * wx + wy * wy + wz * wz));             // sift.c:1032
+                const double ac = fabs(cos_ang);
+                corner = corner < ac ? corner : ac;                               // sift.c:1036
+                const float sgn = d > 0.0 ? 1.0f : -1.0f;
+                vx = vx * sgn; vy = vy * sgn; vz = vz * sgn;
+                R[0 * 3 + i] = vx; R[1 * 3 + i] = vy; R[2 * 3 + i] = vz;
+                v[i][0] = vx; v[i][1] = vy; v[i][2] = vz;
+            }
+            R[0 * 3 + 2] = v[0][1] * v[1][2] - v[0][2] * v[1][1];                 // sift.c:1054
+            R[1 * 3 + 2] = v[0][2] * v[1][0] - v[0][0] * v[1][2];
+            R[2 * 3 + 2] = v[0][0] * v[1][1] - v[0][1] * v[1][0];
+            if (corner < corner_thresh)                                           // sift.c:1100
+                kept = 0;
+        }
+    }
+    if (lane < 9)
+        Rout[(size_t)ci * 9 + lane] = R[lane];
+    if (lane == 0)
+        keep[ci] = kept;
+}
+
+// ---------------------------------------------------------------------------------------
+// extract_descrip  (sift.c:1442-1536): one wave per keypoint.
+//
+// Phase A (64 voxels in parallel): window test, gradient, Gaussian weight, rotation into
+// keypoint space, icosahedron face + barycentrics, the eight trilinear cell weights.
+// Phase B (ordered): for each valid voxel in scan order, 24 lanes (8 cells x 3 face
+// vertices) add mag*w_cell*bary_j into the 768-bin LDS histogram with ds_add_f32.  DS
+// operations of one wave execute in issue order, so every bin receives its contributions
+// in the reference's order and the float sums are bit-identical to the CPU loop.
+// ---------------------------------------------------------------------------------------
+struct FaceRec {
+    float v0[3], e1[3], e2[3], t[3], q[3], e2q, idx[3];
+};
+static_assert(sizeof(FaceRec) == SIFT3D_HIP_FACE_FLOATS * 4, "face record layout");
+
+__constant__ FaceRec c_faces[20];
+__constant__ int c_face_idx[60];
+
+__global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restrict__ levels,
+                                                 const sift3d_hip_kp *__restrict__ kps, uint32_t n,
+                                                 float *__restrict__ out)
+{
+    __shared__ float hist[768];
+    __shared__ float mw[8][65];   // mag * trilinear weight of the eight cells
+    __shared__ float bw[3][65];   // barycentric weights
+    __shared__ int meta[64];      // ix | iy<<2 | iz<<4 | face<<6
+    const uint32_t ki = blockIdx.x;
+    if (ki >= n)
+        return;
+    const int lane = threadIdx.x;
+    const sift3d_hip_kp K = kps[ki];
+    const sift3d_hip_level L = levels[K.level];
+    for (int i = lane; i < 768; i += 64)
+        hist[i] = 0.0f;
+
+    const float sigma = (float)(K.sd * 7.071067812);                  // sift.c:1453
+    const float rad = (float)(2.0 * (double)sigma);                   // sift.c:1454
+    const float half_w = (float)((double)rad / 1.4142135623730951);   // / sqrt(2), sift.c:1455
+    const float desc_w = 2.0f * half_w;
+    const float hist_w = desc_w / 4.0f;                               // / NHIST_PER_DIM
+    const float bin_f = 1.0f / hist_w;
+    const float rad2 = rad * rad;
+    const float sig2 = sigma * sigma;
+    const float *R = K.R; // Rt[i][j] = R[j][i]
+    Box B;
+    bounds_f(K.cx, rad, L.ux, L.nx, B.xs, B.xe);
+    bounds_f(K.cy, rad, L.uy, L.ny, B.ys, B.ye);
+    bounds_f(K.cz, rad, L.uz, L.nz_glob, B.zs, B.ze);
+    const int bx = B.xe - B.xs + 1, by = B.ye - B.ys + 1;
+    const int npl = bx > 0 && by > 0 ? bx * by : 0;
+    // lanes 0..23 of phase B
+    const int pc = lane / 3, pj = lane - 3 * pc;       // cell corner, face vertex
+    const int pdx = (pc >> 2) & 1, pdy = (pc >> 1) & 1, pdz = pc & 1;
+    __syncthreads();
+
+    for (int z = B.zs; z <= B.ze; z++) {
+        const float dz = ((float)z - K.cz) * L.uz;
+        for (int c0 = 0; c0 < npl; c0 += 64) {
+            const int i = c0 + lane;
+            bool ok = false;
+            if (i < npl) {
+                const int yy = i / bx, xx = i - yy * bx;
+                const int x = B.xs + xx, y = B.ys + yy;
+                const float dx = ((float)x - K.cx) * L.ux;
+                const float dy = ((float)y - K.cy) * L.uy;
+                const float sq = dx * dx + dy * dy + dz * dz;
+                if (!(sq > rad2)) {                                        // sift.c:106 (float)
+                    // vkp = Rt * vim (immacros.h:328-340)
+                    const float kx = R[0] * dx + R[3] * dy + R[6] * dz;
+                    const float ky = R[1] * dx + R[4] * dy + R[7] * dz;
+                    const float kz = R[2] * dx + R[5] * dy + R[8] * dz;
+                    const float vbx = (kx + half_w) * bin_f;               // sift.c:1483-1485
+                    const float vby = (ky + half_w) * bin_f;
+                    const float vbz = (kz + half_w) * bin_f;
+                    if (!(vbx < 0 || vby < 0 || vbz < 0 || vbx >= 4.0f || vby >= 4.0f ||
+                          vbz >= 4.0f)) {                                  // sift.c:1488-1492
+                        float gx, gy, gz;
+                        grad_iso(L, x, y, z - L.z_off, gx, gy, gz);
+                        const float w = s3d_expf(-0.5f * sq / sig2);       // sift.c:1498
+                        gx = gx * w; gy = gy * w; gz = gz * w;
+                        const float rx = R[0] * gx + R[3] * gy + R[6] * gz; // sift.c:1502
+                        const float ry = R[1] * gx + R[4] * gy + R[7] * gz;
+                        const float rz = R[2] * gx + R[5] * gy + R[8] * gz;
+                        const float m2 = rx * rx + ry * ry + rz * rz;
+                        if (!(m2 < 1.1920928955078125e-06f)) {             // sift.c:1264
+                            // icos_hist_bin (sift.c:1268-1286) over cart2bary (sift.c:268-297)
+                            int face = -1;
+                            float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+                            for (int f = 0; f < 20; f++) {
+                                const FaceRec &F = c_faces[f];
+                                const float px = ry * F.e2[2] - rz * F.e2[1];
+                                const float py = rz * F.e2[0] - rx * F.e2[2];
+                                const float pz = rx * F.e2[1] - ry * F.e2[0];
+                                const float det = F.e1[0] * px + F.e1[1] * py + F.e1[2] * pz;
+                                if (fabsf(det) < 1.1920928955078125e-06f)   // sift.c:282
+                                    continue;
+                                const float di = 1.0f / det;
+                                const float yb = di * (F.t[0] * px + F.t[1] * py + F.t[2] * pz);
+                                const float zb = di * (rx * F.q[0] + ry * F.q[1] + rz * F.q[2]);
+                                const float xb = 1.0f - yb - zb;
+                                const float kk = F.e2q * di;
+                                if (xb < -1.1920928955078125e-06f || yb < -1.1920928955078125e-06f ||
+                                    zb < -1.1920928955078125e-06f || kk < 0)  // sift.c:1277-1279
+                                    continue;
+                                face = f; b0 = xb; b1 = yb; b2 = zb;
+                                break;
+                            }
+                            if (face >= 0) {
+                                ok = true;
+                                const float mag = sqrtf(m2);                // sift.c:1331
+                                const float fx = vbx - floorf(vbx);         // sift.c:1318-1320
+                                const float fy = vby - floorf(vby);
+                                const float fz = vbz - floorf(vbz);
+                                const float ax[2] = { 1.0f - fx, fx }, ay[2] = { 1.0f - fy, fy },
+                                            az[2] = { 1.0f - fz, fz };
+#pragma unroll
+                                for (int c = 0; c < 8; c++) {
+                                    // weight = wx * wy * wz (sift.c:1361-1363), value = mag * weight * bary
+                                    const float wt = ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1];
+                                    mw[c][lane] = mag * wt;
+                                }
+                                bw[0][lane] = b0; bw[1][lane] = b1; bw[2][lane] = b2;
+                                meta[lane] = (int)vbx | ((int)vby << 2) | ((int)vbz << 4) | (face << 6);
+                            }
+                        }
+                    }
+                }
+            }
+            unsigned long long m = __ballot(ok);
+            if (m == 0ull)
+                continue;
+            __syncthreads();
+            while (m) {
+                const int v = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (lane < 24) {
+                    const int mt = meta[v];
+                    const int cxx = (mt & 3) + pdx, cyy = ((mt >> 2) & 3) + pdy,
+                              czz = ((mt >> 4) & 3) + pdz;
+                    if (cxx < 4 && cyy < 4 && czz < 4) {                     // sift.c:1349-1352
+                        const int bin = c_face_idx[(mt >> 6) * 3 + pj];       // unswapped idx[] (Q1)
+                        const float val = mw[pc][v] * bw[pj][v];              // sift.c:1371-1373
+                        atomicAdd(&hist[(cxx + 4 * cyy + 16 * czz) * 12 + bin], val);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // normalize_desc -> clamp -> normalize_desc (sift.c:1402-1429, 1514-1526).  The double
+    // sum runs in element order on every lane (uniform), as in the reference.
+    const float trunc = 0.2f * 128.0f / 768.0f;                               // sift.c:45
+    for (int pass = 0; pass < 2; pass++) {
+        double norm = 0.0;
+        for (int i = 0; i < 768; i++) {
+            const float el = hist[i];
+            norm += (double)el * (double)el;
+        }
+        norm = sqrt(norm) + 2.220446049250313e-16;                            // DBL_EPSILON
+        const float inv = (float)(1.0 / norm);                                // 1.0f / norm
+        __syncthreads();
+        for (int i = lane; i < 768; i += 64) {
+            float el = hist[i] * inv;
+            if (pass == 0)
+                el = el < trunc ? el : trunc;                                 // sift.c:1520
+            hist[i] = el;
+        }
+        __syncthreads();
+    }
+    for (int i = lane; i < 768; i += 64)
+        out[(size_t)ki * 768 + i] = hist[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// synthetic lattice volume (twin of synth.c:sift3d_amd_synth_lattice_voxel)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t v)
+{
+    v += 0x9E3779B97F4A7C15ull;
+    v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ull;
+    v = (v ^ (v >> 27)) * 0x94D049BB133111EBull;
+    return v ^ (v >> 31);
+}
+
+__device__ __forceinline__ float unit_f(uint64_t h, int k)
+{
+    return (float)((h >> (16 * k)) & 0xFFFF) * (1.0f / 65536.0f);
+}
+
+__global__ __launch_bounds__(256) void k_synth_lattice(float *__restrict__ dst, int nx, int ny,
+                                                       int nz, int z_off, uint64_t seed)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, zl = blockIdx.z, z = zl + z_off;
+    if (x >= nx)
+        return;
+    const int cell = SIFT3D_AMD_SYNTH_CELL;
+    const uint64_t hv = mix64(seed ^ mix64(((uint64_t)(uint32_t)x) | ((uint64_t)(uint32_t)y << 21) |
+                                           ((uint64_t)(uint32_t)z << 42)));
+    float v = 0.05f * unit_f(hv, 0);
+    const int gx = x / cell, gy = y / cell, gz = z / cell;
+    for (int iz = gz - 1; iz <= gz + 1; iz++)
+        for (int iy = gy - 1; iy <= gy + 1; iy++)
+            for (int ix = gx - 1; ix <= gx + 1; ix++) {
+                if (ix < 0 || iy < 0 || iz < 0)
+                    continue;
+                const uint64_t h1 = mix64(seed + 0x51ED270B1ull +
+                                          mix64(((uint64_t)ix) | ((uint64_t)iy << 21) |
+                                                ((uint64_t)iz << 42)));
+                const uint64_t h2 = mix64(h1);
+                const float cx = ((float)ix + unit_f(h1, 0)) * (float)cell;
+                const float cy = ((float)iy + unit_f(h1, 1)) * (float)cell;
+                const float cz = ((float)iz + unit_f(h1, 2)) * (float)cell;
+                const float sg = 1.5f + 2.5f * unit_f(h1, 3);
+                const float a = 2.0f * unit_f(h2, 0) - 1.0f;
+                const float dx = (float)x - cx, dy = (float)y - cy, dz = (float)z - cz;
+                const float q = dx * dx + 1.3f * dy * dy + 0.7f * dz * dz;
+                if (q > 18.0f * sg * sg)
+                    continue;
+                v += a * expf(-q / (2.0f * sg * sg));
+            }
+    dst[(size_t)x + (size_t)nx * ((size_t)y + (size_t)ny * zl)] = v;
+}
+
+// device evaluation of the shared math, for tests
+__global__ void k_test_expf(const float *in, float *out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = s3d_expf(in[i]);
+}
+
+__global__ void k_test_eigen3(const double *A, double *Q, double *L, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        s3d_eigen3(A + 9 * i, Q + 9 * i, L + 3 * i);
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+static int grid_for(size_t n, int per_thread)
+{
+    size_t b = (n / per_thread + 255) / 256;
+    if (b < 1)
+        b = 1;
+    if (b > 256 * 16)
+        b = 256 * 16; // ~16 blocks per CU, grid-stride beyond that
+    return (int)b;
+}
+
+template <int HW>
+static void launch_fir_x_u1(const FirParams &P, const FirTaps &T, hipStream_t st)
+{
+    const int nrows = P.ny * (P.z_hi - P.z_lo);
+    dim3 grid((P.nx + 511) / 512, (nrows + 3) / 4);
+    hipLaunchKernelGGL(k_fir_x_u1<HW>, grid, dim3(256), 0, st, P, T);
+}
+
+template <int HW>
+static void launch_fir_sweep_u1(const FirParams &P, const SweepGeom &G, const FirTaps &T, int V,
+                                hipStream_t st)
+{
+    const int nseg = (G.out_hi - G.out_lo + P.ts - 1) / P.ts;
+    dim3 grid((G.ncols + 255) / 256, nseg);
+    if (V == 4)
+        hipLaunchKernelGGL((k_fir_sweep_u1<HW, 4>), grid, dim3(256), 0, st, P, G, T);
+    else
+        hipLaunchKernelGGL((k_fir_sweep_u1<HW, 1>), grid, dim3(256), 0, st, P, G, T);
+}
+
+// device copies of the dyadic tap tables, keyed by (taps, uf); tiny LRU
+struct DyadSlot {
+    DyadTaps host;
+    DyadTaps *dev;
+    int width;
+    float uf;
+    bool used;
+};
+static DyadSlot g_dyad[128];
+static std::mutex g_dyad_mu;
+static int g_dyad_next = 0;
+
+static const DyadTaps *dyad_table(const float *taps, int width, float uf, hipStream_t st)
+{
+    const int hw = width / 2;
+    std::lock_guard<std::mutex> lock(g_dyad_mu);
+    for (int i = 0; i < 128; i++)
+        if (g_dyad[i].used && g_dyad[i].width == width && g_dyad[i].uf == uf &&
+            memcmp(g_dyad[i].host.k, taps, sizeof(float) * width) == 0)
+            return g_dyad[i].dev;
+    DyadSlot &S = g_dyad[g_dyad_next];
+    g_dyad_next = (g_dyad_next + 1) % 128;
+    memset(&S.host, 0, sizeof(S.host));
+    for (int d = -hw; d <= hw; d++) {
+        // the reference's float expressions at an index where g -+ hw*uf is exact
+        const int g0 = 1 << 10;
+        const float c = (float)g0 - (float)d * uf;
+        const int lo = (int)c;
+        const float frac = c - (float)lo;
+        S.host.k[d + hw] = taps[d + hw];
+        S.host.w0[d + hw] = 1.0f - frac;
+        S.host.w1[d + hw] = frac;
+        S.host.off[d + hw] = lo - g0;
+    }
+    if (!S.dev && hipMalloc((void **)&S.dev, sizeof(DyadTaps)) != hipSuccess)
+        return nullptr;
+    // synchronous w.r.t. the host buffer: the slot may be recycled later
+    if (hipMemcpyAsync(S.dev, &S.host, sizeof(DyadTaps), hipMemcpyHostToDevice, st) != hipSuccess)
+        return nullptr;
+    if (hipStreamSynchronize(st) != hipSuccess)
+        return nullptr;
+    S.width = width;
+    S.uf = uf;
+    S.used = true;
+    return S.dev;
+}
+
+static bool is_dyadic(float uf, int *shift)
+{
+    int e;
+    const float m = frexpf(uf, &e);
+    if (m != 0.5f || e > 1)
+        return false;
+    *shift = 1 - e;
+    return true;
+}
+
+extern "C" {
+
+int sift3d_hip_absmax(const float *d_src, size_t n, float *d_max, void *stream)
+{
+    if (!n)
+        return SIFT3D_SUCCESS;
+    hipLaunchKernelGGL(k_absmax, dim3(grid_for(n, 16)), dim3(256), 0, (hipStream_t)stream, d_src, n,
+                       reinterpret_cast<unsigned *>(d_max));
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_scale(const float *d_src, float *d_dst, size_t n, const float *d_max, void *stream)
+{
+    if (!n)
+        return SIFT3D_SUCCESS;
+    hipLaunchKernelGGL(k_scale, dim3(grid_for(n, 16)), dim3(256), 0, (hipStream_t)stream, d_src,
+                       d_dst, n, d_max);
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_fir(const sift3d_hip_fir_args *a, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!a || !a->src || !a->dst || a->nx < 1 || a->ny < 1 || a->nz < 1 || a->axis < 0 ||
+        a->axis > 2 || a->width < 1 || !(a->width & 1) || a->width > SIFT3D_HIP_MAX_TAPS ||
+        a->z_lo < 0 || a->z_hi > a->nz || a->src == a->dst) {
+        snprintf(g_err, sizeof(g_err), "sift3d_hip_fir: invalid arguments");
+        fprintf(stderr, "sift3d_amd: %s\n", g_err);
+        return SIFT3D_FAILURE;
+    }
+    if (a->z_hi <= a->z_lo)
+        return SIFT3D_SUCCESS;
+    FirParams P;
+    FirTaps T;
+    memset(&T, 0, sizeof(T));
+    memcpy(T.k, a->taps, sizeof(float) * a->width);
+    P.src = a->src; P.dst = a->dst;
+    P.nx = a->nx; P.ny = a->ny; P.nz = a->nz;
+    P.axis = a->axis;
+    P.hw = a->width / 2;
+    P.uf = a->unit_factor;
+    P.uhw = (int)ceilf((float)P.hw * P.uf);           // imutil.c:756-757
+    const int dims[3] = { a->nx, a->ny, a->nz };
+    P.n_glob = a->axis == 2 ? a->n_glob : dims[a->axis];
+    P.off = a->axis == 2 ? a->off : 0;
+    P.z_lo = a->z_lo; P.z_hi = a->z_hi;
+    P.ts = 64;
+    if (a->axis == 2 && (P.off < 0 || P.off + a->nz > P.n_glob)) {
+        snprintf(g_err, sizeof(g_err), "sift3d_hip_fir: slab outside the global axis");
+        fprintf(stderr, "sift3d_amd: %s\n", g_err);
+        return SIFT3D_FAILURE;
+    }
+    const size_t plane = (size_t)a->nx * a->ny;
+    int shift = 0;
+    const bool dyadic = is_dyadic(P.uf, &shift) && shift <= 12 && P.n_glob < (1 << (23 - shift));
+    const bool aligned = (((uintptr_t)a->src | (uintptr_t)a->dst) & 15) == 0;
+
+    // geometry of the strided sweeps (y and z passes)
+    SweepGeom G;
+    int V = 1;
+    if (a->axis == 1) {
+        V = (aligned && (a->nx & 3) == 0) ? 4 : 1;
+        G.cols_inner = a->nx / V;
+        G.ncols = G.cols_inner * (a->z_hi - a->z_lo);
+        G.outer_stride = plane;
+        G.outer_lo = a->z_lo;
+        G.stride = a->nx;
+        G.n_loc = a->ny;
+        G.out_lo = 0; G.out_hi = a->ny;
+    } else if (a->axis == 2) {
+        V = (aligned && (plane & 3) == 0) ? 4 : 1;
+        G.cols_inner = (int)(plane / V);
+        G.ncols = G.cols_inner;
+        G.outer_stride = 0;
+        G.outer_lo = 0;
+        G.stride = plane;
+        G.n_loc = a->nz;
+        G.out_lo = a->z_lo; G.out_hi = a->z_hi;
+    }
+
+    if (a->variant != 1 && P.uf == 1.0f && P.hw >= 1 && P.hw <= 8) {
+        // unit-spaced taps (octave 0): register-window kernels
+        if (a->axis == 0) {
+            switch (P.hw) {
+            case 1: launch_fir_x_u1<1>(P, T, st); break;
+            case 2: launch_fir_x_u1<2>(P, T, st); break;
+            case 3: launch_fir_x_u1<3>(P, T, st); break;
+            case 4: launch_fir_x_u1<4>(P, T, st); break;
+            case 5: launch_fir_x_u1<5>(P, T, st); break;
+            case 6: launch_fir_x_u1<6>(P, T, st); break;
+            case 7: launch_fir_x_u1<7>(P, T, st); break;
+            default: launch_fir_x_u1<8>(P, T, st); break;
+            }
+        } else {
+            switch (P.hw) {
+            case 1: launch_fir_sweep_u1<1>(P, G, T, V, st); break;
+            case 2: launch_fir_sweep_u1<2>(P, G, T, V, st); break;
+            case 3: launch_fir_sweep_u1<3>(P, G, T, V, st); break;
+            case 4: launch_fir_sweep_u1<4>(P, G, T, V, st); break;
+            case 5: launch_fir_sweep_u1<5>(P, G, T, V, st); break;
+            case 6: launch_fir_sweep_u1<6>(P, G, T, V, st); break;
+            case 7: launch_fir_sweep_u1<7>(P, G, T, V, st); break;
+            default: launch_fir_sweep_u1<8>(P, G, T, V, st); break;
+            }
+        }
+    } else if (a->variant != 1 && dyadic && P.hw < 1024) {
+        const DyadTaps *dt = dyad_table(a->taps, a->width, P.uf, st);
+        if (!dt)
+            return fail("dyad_table", hipGetLastError(), __FILE__, __LINE__);
+        if (a->axis == 0) {
+            dim3 grid((a->nx + 255) / 256, a->ny * (a->z_hi - a->z_lo));
+            hipLaunchKernelGGL(k_fir_x_dyad, grid, dim3(256), 0, st, P, dt);
+        } else {
+            dim3 grid((G.ncols + 255) / 256, G.out_hi - G.out_lo);
+            if (V == 4)
+                hipLaunchKernelGGL(k_fir_sweep_dyad<4>, grid, dim3(256), 0, st, P, G, dt);
+            else
+                hipLaunchKernelGGL(k_fir_sweep_dyad<1>, grid, dim3(256), 0, st, P, G, dt);
+        }
+    } else {
+        const size_t total = plane * (size_t)(a->z_hi - a->z_lo);
+        hipLaunchKernelGGL(k_fir_literal, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, T);
+    }
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_subtract_absmax(const float *d_a, const float *d_b, float *d_dst, size_t n,
+                               float *d_absmax, void *stream)
+{
+    if (!n)
+        return SIFT3D_SUCCESS;
+    hipLaunchKernelGGL(k_sub_absmax, dim3(grid_for(n, 16)), dim3(256), 0, (hipStream_t)stream, d_a,
+                       d_b, d_dst, n, reinterpret_cast<unsigned *>(d_absmax));
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_downsample2(const float *d_src, int nx, int ny, float *d_dst, int mx, int my, int mz,
+                           void *stream)
+{
+    if (mx < 1 || my < 1 || mz < 1)
+        return SIFT3D_SUCCESS;
+    hipLaunchKernelGGL(k_downsample2, dim3((mx + 255) / 256, my, mz), dim3(256), 0,
+                       (hipStream_t)stream, d_src, nx, ny, d_dst, mx, my, mz);
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+static ExGeom ex_geom(int nx, int ny, int nz, double peak)
+{
+    ExGeom E;
+    E.nx = nx; E.ny = ny; E.nz = nz;
+    E.wpr = (nx + 63) / 64;
+    E.nwords = (uint32_t)((size_t)nz * ny * E.wpr);
+    E.nblk = (E.nwords + EX_WPB - 1) / EX_WPB;
+    E.peak_thresh = peak;
+    return E;
+}
+
+size_t sift3d_hip_extrema_work_bytes(int nx, int ny, int nz, int nlevels)
+{
+    const ExGeom E = ex_geom(nx, ny, nz, 0.0);
+    return (size_t)nlevels * ((size_t)E.nwords * 8 + (size_t)E.nblk * 4) + 256;
+}
+
+int sift3d_hip_extrema(const sift3d_hip_extrema_level *levels, int nlevels, int nx, int ny, int nz,
+                       double peak_thresh, sift3d_hip_cand *d_out, uint32_t cap, uint32_t *d_count,
+                       void *d_work, size_t work_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (nlevels < 1 || nlevels > 8 || (size_t)nx * ny * nz >= (1ull << 32) ||
+        work_bytes < sift3d_hip_extrema_work_bytes(nx, ny, nz, nlevels)) {
+        snprintf(g_err, sizeof(g_err), "sift3d_hip_extrema: invalid arguments");
+        fprintf(stderr, "sift3d_amd: %s\n", g_err);
+        return SIFT3D_FAILURE;
+    }
+    const ExGeom E = ex_geom(nx, ny, nz, peak_thresh);
+    ExLevels LV;
+    memset(&LV, 0, sizeof(LV));
+    for (int i = 0; i < nlevels; i++)
+        LV.lv[i] = levels[i];
+    unsigned long long *masks = reinterpret_cast<unsigned long long *>(d_work);
+    uint32_t *blk = reinterpret_cast<uint32_t *>(masks + (size_t)nlevels * E.nwords);
+    hipLaunchKernelGGL(k_extrema_mask, dim3(E.nblk, nlevels), dim3(256), 0, st, LV, E, masks, blk);
+    hipLaunchKernelGGL(k_extrema_scan, dim3(1), dim3(1024), 0, st, blk, E.nblk * (uint32_t)nlevels,
+                       d_count);
+    hipLaunchKernelGGL(k_extrema_emit, dim3(E.nblk, nlevels), dim3(256), 0, st, LV, E, masks, blk,
+                       d_out, cap);
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_orient(const sift3d_hip_level *d_levels, const sift3d_hip_cand *d_cand, uint32_t n,
+                      double corner_thresh, float *d_R, int32_t *d_keep, void *stream)
+{
+    if (!n)
+        return SIFT3D_SUCCESS;
+    hipLaunchKernelGGL(k_orient, dim3(n), dim3(64), 0, (hipStream_t)stream, d_levels, d_cand, n,
+                       corner_thresh, d_R, d_keep);
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_set_mesh(const float *faces)
+{
+    int idx[60];
+    for (int f = 0; f < 20; f++)
+        for (int j = 0; j < 3; j++)
+            idx[f * 3 + j] = (int)faces[f * SIFT3D_HIP_FACE_FLOATS + 16 + j];
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_faces), faces, sizeof(FaceRec) * 20));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_face_idx), idx, sizeof(idx)));
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d_kp, uint32_t n,
+                        float *d_hist, void *stream)
+{
+    if (!n)
+        return SIFT3D_SUCCESS;
+    hipLaunchKernelGGL(k_describe, dim3(n), dim3(64), 0, (hipStream_t)stream, d_levels, d_kp, n,
+                       d_hist);
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_synth_lattice(float *d_dst, int nx, int ny, int nz, int z_off, uint64_t seed,
+                             void *stream)
+{
+    hipLaunchKernelGGL(k_synth_lattice, dim3((nx + 255) / 256, ny, nz), dim3(256), 0,
+                       (hipStream_t)stream, d_dst, nx, ny, nz, z_off, seed);
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+void sift3d_amd_host_expf(const float *in, float *out, size_t n)
+{
+    for (size_t i = 0; i < n; i++)
+        out[i] = s3d_expf(in[i]);
+}
+
+void sift3d_amd_host_eigen3(const double *A9, double *Q9, double *L3) { s3d_eigen3(A9, Q9, L3); }
+
+int sift3d_hip_test_expf(const float *d_in, float *d_out, size_t n, void *stream)
+{
+    hipLaunchKernelGGL(k_test_expf, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, d_in, d_out, n);
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_test_eigen3(const double *d_A9, double *d_Q9, double *d_L3, size_t n, void *stream)
+{
+    hipLaunchKernelGGL(k_test_eigen3, dim3((unsigned)((n + 63) / 64)), dim3(64), 0,
+                       (hipStream_t)stream, d_A9, d_Q9, d_L3, n);
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+} // extern "C"

@@ -63,8 +63,9 @@ S3D_HD uint64_t s3d_f64_as_u64(double d)
     return u;
 }
 
-/* expf for finite arguments in (-87, 88); outside that range the limits
- * (0 / +inf) are returned without the errno/fenv side effects of libm.
+/* expf.  Arguments in [-150, 88.72] take the table path (denormal results are
+ * produced by the final double -> float conversion, as in glibc); outside it the
+ * limits (0 / +inf) are returned without libm's errno/fenv side effects.
  * `use_fma` selects the contraction pattern of glibc's FMA-enabled build
  * (what an x86-64 host with FMA3 dispatches to). */
 S3D_HD float s3d_expf_impl(float x, int use_fma)
@@ -77,9 +78,9 @@ S3D_HD float s3d_expf_impl(float x, int use_fma)
     double xd, z, kd, r, r2, y, s;
     uint64_t ki, t;
 
-    if (!(x > -87.0f))
+    if (!(x >= -150.0f))
         return x != x ? x : 0.0f;
-    if (x > 88.0f)
+    if (x > 0x1.62e42ep6f)
         return INFINITY;
     xd = (double)x;
     z = inv_ln2_n * xd;

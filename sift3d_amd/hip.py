@@ -1,0 +1,144 @@
+"""ctypes bindings of the device-level stage ABI (include/sift3d_amd.h, `sift3d_hip_*`).
+
+Device buffers are torch tensors on the current HIP device (torch is only the allocator /
+stream / process-group plumbing); every call takes raw device pointers and runs on torch's
+current stream, so results are ordered with other torch work on that stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+
+MAX_TAPS = 65
+FACE_FLOATS = 19
+
+
+class FirArgs(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("nx", C.c_int), ("ny", C.c_int),
+                ("nz", C.c_int), ("axis", C.c_int), ("width", C.c_int),
+                ("taps", C.POINTER(C.c_float)), ("unit_factor", C.c_float), ("n_glob", C.c_int),
+                ("off", C.c_int), ("z_lo", C.c_int), ("z_hi", C.c_int), ("variant", C.c_int)]
+
+
+class ExtremaLevel(C.Structure):
+    _fields_ = [("prev", C.c_void_p), ("cur", C.c_void_p), ("next", C.c_void_p),
+                ("d_absmax", C.c_void_p), ("z_lo", C.c_int), ("z_hi", C.c_int), ("tag", C.c_int)]
+
+
+class Level(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+                ("z_off", C.c_int), ("nz_glob", C.c_int), ("ux", C.c_float), ("uy", C.c_float),
+                ("uz", C.c_float), ("octave", C.c_int), ("sd", C.c_double)]
+
+
+CAND_DTYPE = np.dtype([("idx", "u4"), ("tag", "i4"), ("val", "f4")])
+KP_DTYPE = np.dtype([("R", "f4", (9,)), ("cx", "f4"), ("cy", "f4"), ("cz", "f4"),
+                     ("level", "i4"), ("sd", "f8")], align=True)
+LEVEL_DTYPE = np.dtype([("data", "u8"), ("nx", "i4"), ("ny", "i4"), ("nz", "i4"),
+                        ("z_off", "i4"), ("nz_glob", "i4"), ("ux", "f4"), ("uy", "f4"),
+                        ("uz", "f4"), ("octave", "i4"), ("sd", "f8")], align=True)
+assert LEVEL_DTYPE.itemsize == C.sizeof(Level)
+assert KP_DTYPE.itemsize == 64 and CAND_DTYPE.itemsize == 12
+
+_bound = None
+
+
+def lib():
+    global _bound
+    if _bound is not None:
+        return _bound
+    L = _native.load()
+    vp = C.c_void_p
+    sig = {
+        "sift3d_hip_device_count": (C.c_int, []),
+        "sift3d_hip_set_device": (C.c_int, [C.c_int]),
+        "sift3d_hip_malloc": (vp, [C.c_size_t]),
+        "sift3d_hip_free": (None, [vp]),
+        "sift3d_hip_host_alloc": (vp, [C.c_size_t]),
+        "sift3d_hip_host_free": (None, [vp]),
+        "sift3d_hip_memcpy_h2d": (C.c_int, [vp, vp, C.c_size_t, vp]),
+        "sift3d_hip_memcpy_d2h": (C.c_int, [vp, vp, C.c_size_t, vp]),
+        "sift3d_hip_memcpy_d2d": (C.c_int, [vp, vp, C.c_size_t, vp]),
+        "sift3d_hip_memset": (C.c_int, [vp, C.c_int, C.c_size_t, vp]),
+        "sift3d_hip_stream_create": (vp, []),
+        "sift3d_hip_stream_destroy": (None, [vp]),
+        "sift3d_hip_stream_sync": (C.c_int, [vp]),
+        "sift3d_hip_event_create": (vp, []),
+        "sift3d_hip_event_destroy": (None, [vp]),
+        "sift3d_hip_event_record": (C.c_int, [vp, vp]),
+        "sift3d_hip_event_elapsed_ms": (C.c_double, [vp, vp]),
+        "sift3d_hip_absmax": (C.c_int, [vp, C.c_size_t, vp, vp]),
+        "sift3d_hip_scale": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
+        "sift3d_hip_fir": (C.c_int, [C.POINTER(FirArgs), vp]),
+        "sift3d_hip_subtract_absmax": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp]),
+        "sift3d_hip_downsample2": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+        "sift3d_hip_extrema_work_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+        "sift3d_hip_extrema": (C.c_int, [C.POINTER(ExtremaLevel), C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_double, vp, C.c_uint32, vp, vp, C.c_size_t, vp]),
+        "sift3d_hip_orient": (C.c_int, [vp, vp, C.c_uint32, C.c_double, vp, vp, vp]),
+        "sift3d_hip_describe": (C.c_int, [vp, vp, C.c_uint32, vp, vp]),
+        "sift3d_hip_set_mesh": (C.c_int, [C.POINTER(C.c_float)]),
+        "sift3d_hip_synth_lattice": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, vp]),
+        "sift3d_hip_test_expf": (C.c_int, [vp, vp, C.c_size_t, vp]),
+        "sift3d_hip_test_eigen3": (C.c_int, [vp, vp, vp, C.c_size_t, vp]),
+        "sift3d_hip_last_error": (C.c_char_p, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _bound = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, lib().sift3d_hip_last_error().decode()))
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def fir(src, dst, axis, taps, unit_factor=1.0, n_glob=None, off=0, z_lo=0, z_hi=None, variant=0):
+    """One 1-D pass (convolve_sep_gen, imutil.c:742-861) on torch CUDA tensors [nz, ny, nx]."""
+    nz, ny, nx = src.shape
+    assert src.is_contiguous() and dst.is_contiguous() and src.shape == dst.shape
+    taps = np.ascontiguousarray(taps, np.float32)
+    a = FirArgs(src.data_ptr(), dst.data_ptr(), nx, ny, nz, axis, len(taps),
+                taps.ctypes.data_as(C.POINTER(C.c_float)), float(np.float32(unit_factor)),
+                nz if n_glob is None else n_glob, off, z_lo, nz if z_hi is None else z_hi, variant)
+    _check(lib().sift3d_hip_fir(C.byref(a), current_stream()), "sift3d_hip_fir")
+    return dst
+
+
+def absmax(src, out):
+    _check(lib().sift3d_hip_absmax(src.data_ptr(), src.numel(), out.data_ptr(), current_stream()),
+           "sift3d_hip_absmax")
+
+
+def scale(src, dst, d_max):
+    _check(lib().sift3d_hip_scale(src.data_ptr(), dst.data_ptr(), src.numel(), d_max.data_ptr(),
+                                  current_stream()), "sift3d_hip_scale")
+
+
+def subtract_absmax(a, b, dst, d_absmax=None):
+    _check(lib().sift3d_hip_subtract_absmax(a.data_ptr(), b.data_ptr(), dst.data_ptr(), a.numel(),
+                                            d_absmax.data_ptr() if d_absmax is not None else None,
+                                            current_stream()), "sift3d_hip_subtract_absmax")
+
+
+def downsample2(src, dst):
+    nz, ny, nx = src.shape
+    mz, my, mx = dst.shape
+    _check(lib().sift3d_hip_downsample2(src.data_ptr(), nx, ny, dst.data_ptr(), mx, my, mz,
+                                        current_stream()), "sift3d_hip_downsample2")
+
+
+def synth_lattice(dst, z_off=0, seed=1):
+    nz, ny, nx = dst.shape
+    _check(lib().sift3d_hip_synth_lattice(dst.data_ptr(), nx, ny, nz, z_off, seed, current_stream()),
+           "sift3d_hip_synth_lattice")
+    return dst

@@ -1,0 +1,347 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+  (1) the committed golden vectors of the unmodified reference (tests/golden/), and
+  (2) the oracle (oracle/sift3d_oracle.c, itself pinned to those vectors) on seeded inputs.
+
+Bar (BASELINE.json north_star): bit-exact float32 pyramid, candidate counts, keypoint
+indices / scales / strengths; orientation and descriptor floats within 1e-5 relative
+(the tolerance is written next to each check; in practice both are bit-exact too because
+window sums are accumulated in the reference's order).
+"""
+import json
+
+import numpy as np
+import pytest
+
+from tests import util
+from tests.test_oracle_golden import check_detect_against_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5  # north_star: "descriptor and orientation floats within 1e-5 relative"
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from sift3d_amd import api, hip
+    if not torch.cuda.is_available() or not api.device_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    hip.lib()
+    return api, hip, torch
+
+
+# ----------------------------------------------------------------------------------------
+# device math
+# ----------------------------------------------------------------------------------------
+def test_device_expf_matches_host_libm(gpu):
+    api, hip, torch = gpu
+    rng = np.random.default_rng(1)
+    x = np.concatenate([-rng.random(1 << 20).astype(np.float32) * 30.0,
+                        -np.exp(rng.random(1 << 18) * 10 - 8).astype(np.float32),
+                        np.array([0.0, -0.0, -1e-30, -87.5, -100.0, -1e30], np.float32)])
+    want = np.exp(x.astype(np.float32))  # numpy float32 exp == libm expf on this platform?
+    # authoritative host value: the library's own host evaluation, which tests/test_host_api.py
+    # pins against libm expf bit-for-bit
+    host = np.empty_like(x)
+    api.lib().sift3d_amd_host_expf(x, host, x.size)
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty_like(d_in)
+    assert hip.lib().sift3d_hip_test_expf(d_in.data_ptr(), d_out.data_ptr(), x.size,
+                                          hip.current_stream()) == 0
+    got = d_out.cpu().numpy()
+    np.testing.assert_array_equal(got, host)
+    assert np.abs(got - want).max() <= 1e-6
+
+
+def test_device_eigen3_matches_host(gpu):
+    api, hip, torch = gpu
+    rng = np.random.default_rng(2)
+    n = 4096
+    m = rng.standard_normal((n, 3, 3))
+    A = m @ m.transpose(0, 2, 1)
+    Qh = np.zeros((n, 9)); Lh = np.zeros((n, 3))
+    for i in range(n):
+        api.lib().sift3d_amd_host_eigen3(np.ascontiguousarray(A[i].reshape(9)), Qh[i], Lh[i])
+    dA = torch.from_numpy(A.reshape(n, 9).copy()).cuda()
+    dQ = torch.empty((n, 9), dtype=torch.float64, device="cuda")
+    dL = torch.empty((n, 3), dtype=torch.float64, device="cuda")
+    assert hip.lib().sift3d_hip_test_eigen3(dA.data_ptr(), dQ.data_ptr(), dL.data_ptr(), n,
+                                            hip.current_stream()) == 0
+    np.testing.assert_array_equal(dL.cpu().numpy(), Lh)
+    np.testing.assert_array_equal(dQ.cpu().numpy(), Qh)
+    w = np.linalg.eigvalsh(A)
+    np.testing.assert_allclose(Lh, w, rtol=1e-10, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------------------
+# 1-D FIR stage: every kernel variant vs the reference's golden outputs and the oracle
+# ----------------------------------------------------------------------------------------
+def _fir_gpu(hip, torch, vol, taps, axis, uf, variant=0, **kw):
+    src = torch.from_numpy(np.ascontiguousarray(vol)).cuda()
+    dst = torch.full_like(src, float("nan"))
+    hip.fir(src, dst, axis, taps, unit_factor=uf, variant=variant, **kw)
+    torch.cuda.synchronize()
+    return dst.cpu().numpy()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_fir_golden(gpu, variant):
+    """g2_fir.npz: outputs of the reference's convolve_sep (three widths, units 1/2/4,
+    asymmetric taps, a 9-long axis under the 17-tap filter)."""
+    api, hip, torch = gpu
+    g = util.load("g2_fir")
+    vol = g["vol"]
+    n = 0
+    for key in g.files:
+        if not key.startswith("axis"):
+            continue
+        ax = int(key[4])
+        _, w, u = key.split("_")
+        taps = g["taps_asym"] if w == "asym" else g["taps_" + w]
+        got = _fir_gpu(hip, torch, vol, taps, ax, np.float32(1.0 / float(u[1:])), variant)
+        np.testing.assert_array_equal(got, g[key], err_msg=key)
+        n += 1
+    assert n == 33
+
+
+@pytest.mark.parametrize("shape", [(40, 36, 128), (33, 30, 516), (16, 24, 64), (19, 21, 23),
+                                   (70, 64, 64)])
+def test_fir_fast_paths_vs_oracle(gpu, oracle_mod, shape):
+    """All specialised kernels (x register-window, y/z register-ring, dyadic tables) on
+    shapes that exercise vector / scalar paths, partial segments and short axes."""
+    api, hip, torch = gpu
+    rng = np.random.default_rng(sum(shape))
+    vol = rng.standard_normal(shape).astype(np.float32)
+    for sigma in (0.5387011637869722, 0.9732939207323564, 1.5450077936447955,
+                  2.4525469969308156):
+        taps = oracle_mod.gauss_taps(sigma)
+        for uf in (1.0, 0.5, 0.25, 0.125):
+            for ax in range(3):
+                want, r = oracle_mod.fir_axis(vol, taps, ax, uf=np.float32(uf), mode=0)
+                assert r == 0
+                got = _fir_gpu(hip, torch, vol, taps, ax, np.float32(uf))
+                np.testing.assert_array_equal(got, want, err_msg="sigma %g uf %g axis %d"
+                                              % (sigma, uf, ax))
+
+
+def test_fir_non_dyadic_literal(gpu, oracle_mod):
+    """Anisotropic units give non-dyadic unit factors: the literal kernel with the
+    reference's coordinate round trip (imutil.c:811-817)."""
+    api, hip, torch = gpu
+    rng = np.random.default_rng(5)
+    vol = rng.standard_normal((17, 20, 24)).astype(np.float32)
+    taps = oracle_mod.gauss_taps(1.2262734984654078)
+    for units in ((1.0, 1.5, 0.7), (3.0, 0.9, 6.0)):
+        for ax in range(3):
+            uf = np.float32(1.0 / units[ax])
+            want, r = oracle_mod.fir_axis(vol, taps, ax, uf=uf, mode=0)
+            got = _fir_gpu(hip, torch, vol, taps, ax, uf)
+            np.testing.assert_array_equal(got, want)
+
+
+def test_fir_slab_z(gpu, oracle_mod):
+    """Z-slab form: local buffer + halo, global mirror rules -> identical to unsharded."""
+    api, hip, torch = gpu
+    rng = np.random.default_rng(9)
+    nz = 48
+    vol = rng.standard_normal((nz, 20, 32)).astype(np.float32)
+    for sigma, uf in ((2.4525469969308156, 1.0), (1.5450077936447955, 0.5), (0.9732939207323564, 1.0)):
+        taps = oracle_mod.gauss_taps(sigma)
+        whole, _ = oracle_mod.fir_axis(vol, taps, 2, uf=np.float32(uf), mode=0)
+        reach = int(np.ceil((len(taps) // 2) * uf)) + 1
+        for z0, z1 in ((0, 16), (16, 32), (32, 48)):
+            lo, hi = max(0, z0 - reach), min(nz, z1 + reach)
+            got = _fir_gpu(hip, torch, vol[lo:hi], taps, 2, np.float32(uf), n_glob=nz, off=lo,
+                           z_lo=z0 - lo, z_hi=z1 - lo)
+            np.testing.assert_array_equal(got[z0 - lo:z1 - lo], whole[z0:z1])
+
+
+def test_scale_dog_downsample(gpu, oracle_mod):
+    api, hip, torch = gpu
+    rng = np.random.default_rng(3)
+    a = (rng.standard_normal((18, 21, 37)) * 3).astype(np.float32)
+    b = rng.standard_normal((18, 21, 37)).astype(np.float32)
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    mx = torch.zeros(1, device="cuda")
+    hip.absmax(da, mx)
+    assert mx.item() == np.abs(a).max()
+    out = torch.empty_like(da)
+    hip.scale(da, out, mx)
+    np.testing.assert_array_equal(out.cpu().numpy(), a / np.abs(a).max())
+    dm = torch.zeros(1, device="cuda")
+    hip.subtract_absmax(da, db, out, dm)
+    np.testing.assert_array_equal(out.cpu().numpy(), a - b)
+    assert dm.item() == np.abs(a - b).max()
+    ds = torch.empty((9, 10, 18), device="cuda")
+    hip.downsample2(da, ds)
+    np.testing.assert_array_equal(ds.cpu().numpy(), oracle_mod.downsample(a))
+    z = torch.zeros_like(da)
+    mz = torch.zeros(1, device="cuda")
+    hip.absmax(z, mz)
+    hip.scale(z, out, mz)  # all-zero input: no division (imutil.c:706-707)
+    assert float(out.abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------------------
+# end to end through the drop-in C API
+# ----------------------------------------------------------------------------------------
+def _run_api(api, vol, units=(1, 1, 1), params=None, device_input=False):
+    det = api.Detector(**(params or {}))
+    kp = api.KeypointStore()
+    if device_input:
+        import torch
+        d = torch.from_numpy(np.ascontiguousarray(vol)).cuda()
+        nz, ny, nx = vol.shape
+        rc = det.detect_keypoints_device(d.data_ptr(), nx, ny, nz, kp, units)
+        torch.cuda.synchronize()
+    else:
+        rc = det.detect_keypoints(api.Image.from_array(vol, units), kp)
+    return det, kp, rc
+
+
+@pytest.mark.parametrize("name", ["g3_64", "g3_70x50x41", "g3_aniso", "g3_params",
+                                  "g3_lattice48", "g5_128"])
+def test_detect_describe_golden(gpu, oracle_mod, name):
+    """Against the reference's own outputs: every pyramid level (sha1 digests + small levels
+    in full), candidate count, the keypoint list incl. the stale-strength quirk, R,
+    descriptors, sort order."""
+    api, hip, torch = gpu
+    g = util.load(name)
+    vol = util.golden_input(g, oracle_mod)
+    params = util.golden_params(g)
+    det, kp, rc = _run_api(api, vol, tuple(g["units"]), params)
+    assert rc == 0
+    k = kp.records()
+    # candidates are not part of the public API; their count is, and the oracle's list is
+    # checked against the same fixture in tests/test_oracle_golden.py
+    assert det.num_candidates() == len(g["cand_sd"])
+    K = params.get("num_kp_levels", 3)
+    num_oct = int(g["num_octaves"])
+    dig = json.loads(str(g["digests"]))
+    for key, want in dig.items():
+        if key == "IM":
+            a = det.level(2, 0, 0)
+        else:
+            o, s = key[2:].split("_")
+            a = det.level(0 if key[0] == "G" else 1, int(o[1:]), int(s[1:]))
+        assert util.digest(a) == want, "level %s differs from the reference" % key
+    with pytest.raises(IndexError):
+        det.level(0, num_oct, 0)
+    np.testing.assert_array_equal(np.stack([k["o"], k["s"]], 1), g["kp_os"])
+    np.testing.assert_array_equal(np.stack([k[f] for f in ("xd", "yd", "zd", "sd")], 1),
+                                  g["kp_xyzsd"])
+    np.testing.assert_array_equal(k["strength"], g["kp_strength"])  # quirk Q2 included
+    assert util.rel_err(k["R"], g["kp_R"]) <= RTOL
+    np.testing.assert_array_equal(kp.to_mat_rm(), g["kp_mat"])
+    desc = api.DescriptorStore()
+    assert det.extract_descriptors(kp, desc) == 0
+    m = desc.to_mat_rm()
+    assert m.shape == (len(k), 771) and m.dtype == np.float32
+    np.testing.assert_array_equal(m[:, :3].astype(np.float64), g["desc_xyzsd"][:, :3].astype(np.float32))
+    idx = g["desc_idx"]
+    assert util.rel_err(m[idx, 3:], g["desc_hist"]) <= RTOL
+    np.testing.assert_allclose(m[:, 3:].astype(np.float64).sum(1), g["desc_rowsum"], rtol=1e-5)
+    # in practice: bit-exact
+    assert np.mean(m[idx, 3:] == g["desc_hist"]) > 0.999
+    assert np.mean(k["R"] == g["kp_R"]) > 0.999
+    for lim in (0, 10):
+        det2, kp2, rc = _run_api(api, vol, tuple(g["units"]), params)
+        kp2.sort_by_strength(lim)
+        k2 = kp2.records()
+        np.testing.assert_array_equal(np.stack([k2["o"], k2["s"]], 1), g["sort%d_os" % lim])
+        np.testing.assert_array_equal(np.stack([k2[f] for f in ("xd", "yd", "zd", "sd")], 1),
+                                      g["sort%d_xyzsd" % lim])
+        np.testing.assert_array_equal(k2["strength"], g["sort%d_strength" % lim])
+
+
+@pytest.mark.parametrize("n,gen", [(96, "survey"), (160, "lattice"), ((100, 72, 90), "survey")])
+def test_detect_describe_vs_oracle(gpu, oracle_mod, n, gen):
+    api, hip, torch = gpu
+    vol = oracle_mod.synth_survey(n) if gen == "survey" else oracle_mod.synth_lattice(n, seed=3)
+    det, kp, rc = _run_api(api, vol, device_input=True)
+    assert rc == 0
+    o = oracle_mod.Oracle()
+    assert o.detect(vol) == 0
+    for oc in range(o.num_octaves):
+        for s in range(-1, 5):
+            np.testing.assert_array_equal(det.level(0, oc, s), o.level(0, oc, s)[0],
+                                          err_msg="G %d %d" % (oc, s))
+        for s in range(-1, 4):
+            np.testing.assert_array_equal(det.level(1, oc, s), o.level(1, oc, s)[0],
+                                          err_msg="D %d %d" % (oc, s))
+    assert det.num_candidates() == len(o.candidates())
+    k, ok = kp.records(), o.keypoints()
+    assert len(k) == len(ok) and len(k) > 20
+    for f in ("o", "s", "xd", "yd", "zd", "sd", "strength"):
+        np.testing.assert_array_equal(k[f], ok[f], err_msg=f)
+    assert util.rel_err(k["R"], ok["R"]) <= RTOL
+    desc = api.DescriptorStore()
+    assert det.extract_descriptors(kp, desc) == 0
+    assert o.describe() == 0
+    m, om = desc.to_mat_rm(), o.desc_mat()
+    assert util.rel_err(m, om) <= RTOL
+    assert np.mean(m == om) > 0.999
+    # describe after sort+truncate (the CLI's order, cli/kpSift3D.c:122)
+    kp.sort_by_strength(25)
+    o.sort_by_strength(25)
+    assert det.extract_descriptors(kp, desc) == 0 and o.describe() == 0
+    assert util.rel_err(desc.to_mat_rm(), o.desc_mat()) <= RTOL
+
+
+def test_g5_256_golden(gpu, oracle_mod):
+    """BASELINE configs[1] (256^3, detect+describe, 1x MI355X) against the reference."""
+    if not util.have("g5_256"):
+        pytest.skip("g5_256 fixture not generated")
+    api, hip, torch = gpu
+    g = util.load("g5_256")
+    vol = util.golden_input(g, oracle_mod)
+    det, kp, rc = _run_api(api, vol, device_input=True)
+    assert rc == 0
+    assert det.num_candidates() == len(g["cand_sd"]) == 13082
+    k = kp.records()
+    assert len(k) == 3481
+    np.testing.assert_array_equal(np.stack([k["o"], k["s"]], 1), g["kp_os"])
+    np.testing.assert_array_equal(np.stack([k[f] for f in ("xd", "yd", "zd", "sd")], 1),
+                                  g["kp_xyzsd"])
+    np.testing.assert_array_equal(k["strength"], g["kp_strength"])
+    assert util.rel_err(k["R"], g["kp_R"]) <= RTOL
+    dig = json.loads(str(g["digests"]))
+    for key in ("G_o0_s4", "G_o1_s2", "D_o0_s1", "D_o5_s3", "G_o3_s-1"):
+        o, s = key[2:].split("_")
+        a = det.level(0 if key[0] == "G" else 1, int(o[1:]), int(s[1:]))
+        assert util.digest(a) == dig[key], key
+    desc = api.DescriptorStore()
+    assert det.extract_descriptors(kp, desc) == 0
+    m = desc.to_mat_rm()
+    idx = g["desc_idx"]
+    assert util.rel_err(m[idx, 3:], g["desc_hist"]) <= RTOL
+    np.testing.assert_allclose(m[:, 3:].astype(np.float64).sum(1), g["desc_rowsum"], rtol=1e-5)
+
+
+def test_reuse_and_errors(gpu, oracle_mod):
+    """Detector / store reuse across images of different size, and the failure cases of
+    SURVEY.md section 8(b)."""
+    api, hip, torch = gpu
+    det = api.Detector()
+    kp = api.KeypointStore()
+    desc = api.DescriptorStore()
+    assert det.extract_descriptors(kp, desc) == -1            # no keypoints, no pyramid
+    for n in (40, 24, 40):
+        vol = oracle_mod.synth_survey(n)
+        assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
+        o = oracle_mod.Oracle()
+        o.detect(vol)
+        np.testing.assert_array_equal(kp.to_mat_rm(), o.kp_mat())
+    assert det.detect_keypoints(api.Image.from_array(np.zeros((7, 16, 16), np.float32)), kp) == -1
+    im2 = api.Image(16, 16, 16, 2)
+    assert det.detect_keypoints(im2, kp) == -1                # nc != 1
+    assert det.detect_keypoints(api.Image.from_array(np.zeros((16, 16, 16), np.float32)), kp) == 0
+    assert len(kp) == 0
+    assert det.extract_descriptors(kp, desc) == -1            # zero keypoints (sift.c:1178)
+    assert det.set_sigma_n(5.0) == -1                         # sigma_n too large for sigma0
+    assert det.set_num_kp_levels(2) == 0                      # reallocates with an image set
+    vol = oracle_mod.synth_survey(32)
+    assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
+    o = oracle_mod.Oracle(num_kp_levels=2)
+    o.detect(vol)
+    np.testing.assert_array_equal(kp.to_mat_rm(), o.kp_mat())
