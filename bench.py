@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- SIFT3D detect+describe throughput on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus 1 --steps K --warmup W            # one GPU, 512^3 (headline)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (sift3d_detect_keypoints + sift3d_extract_descriptors
+through the drop-in C API) over one synthetic float32 volume that is already resident in
+HBM when the timed region starts.  N = 1: the 512^3 volume BASELINE.json's metric is quoted
+on (configs[2]).  N > 1: every rank owns one Z-slab of 512 planes of a 512 x 512 x (512 N)
+volume (weak scaling; halo exchange + keypoint gather over RCCL, sift3d_amd/sharded.py).
+
+Rank 0 prints ONE JSON line: metric/value (Mvoxel/s, whole job), ms_per_step, plus
+  roofline     the dominant pyramid kernel: algorithmic bytes per launch (8 B/voxel per 1-D
+               pass) / its average launch time measured here with HIP events,
+               against the 8 TB/s HBM3E peak; `pyramid` = the same ratio for the whole
+               Gaussian pyramid build (21.63 GB algorithmic at 512^3)
+  cpu_baseline the unmodified reference (oracle/_ref, kind "reference") or the oracle
+               restatement (kind "port") timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+# CPU-baseline threading: one GPU's share of the host (16 cores on the GPU box); must be set
+# before libgomp / OpenBLAS are loaded.  The reference's LAPACK is called from every OpenMP
+# thread, and SciPy's OpenBLAS supports at most 128 callers.
+CPU_THREADS = min(16, os.cpu_count() or 1)
+os.environ.setdefault("OMP_NUM_THREADS", str(CPU_THREADS))
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+
+import numpy as np  # noqa: E402
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def pyramid_algorithmic_bytes(nx, ny, nz):
+    """24 B/voxel/blur (3 passes x (4 B read + 4 B write)); 6 blurs on octave 0, 5 on each
+    later octave (SURVEY.md 8d / BASELINE.md section 3)."""
+    mn = min(nx, ny, nz)
+    num_oct = int(np.log2(mn)) - 3 + 1
+    total = 0
+    d = [nx, ny, nz]
+    for o in range(num_oct):
+        n = d[0] * d[1] * d[2]
+        total += 24 * n * (6 if o == 0 else 5)
+        d = [v // 2 for v in d]
+    return total
+
+
+def kernel_microbench(torch, hip, n, reps=10):
+    """Each octave-0 FIR kernel instance at the headline size, timed with HIP events on the
+    stream it is launched on (torch's current stream)."""
+    from sift3d_amd import api
+    sig = [0.5387011637869722, 0.9732939207323564, 1.2262734984654078, 1.5450077936447955,
+           1.9465878414647133, 2.4525469969308156]
+    src = torch.empty((n, n, n), device="cuda")
+    dst = torch.empty_like(src)
+    hip.synth_lattice(src, 0, 11)
+    out = []
+    for s in sig:
+        hw = max(int(np.ceil(3 * s)), 1)
+        x = np.arange(-hw, hw + 1) / s
+        taps = np.exp(-0.5 * x * x).astype(np.float32)
+        taps /= taps.sum()
+        for ax, nm in enumerate(("k_fir_x_u1", "k_fir_sweep_u1(y)", "k_fir_sweep_u1(z)")):
+            hip.fir(src, dst, ax, taps)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                hip.fir(src, dst, ax, taps)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            out.append(dict(kernel="%s<%d>" % (nm, hw), taps=2 * hw + 1, axis=ax, avg_ms=round(ms, 4),
+                            algorithmic_GB=round(8.0 * n ** 3 / 1e9, 4),
+                            achieved_GBs=round(8.0 * n ** 3 / 1e9 / (ms * 1e-3), 1)))
+    del src, dst
+    return out
+
+
+def cpu_baseline(budget_n=128):
+    """The reference's CPU path on a bounded sample of the same kind of volume."""
+    threads = int(os.environ.get("OMP_NUM_THREADS", CPU_THREADS))
+    from oracle import sift3d_oracle as so
+    vol = so.synth_lattice(budget_n, seed=11)
+    ref_lib = os.path.join(ROOT, "oracle", "_ref", "libsift3d_refprobe.so")
+    if os.path.exists(ref_lib):
+        try:
+            from oracle import refprobe
+            p = refprobe.Probe()
+            t0 = time.time()
+            assert p.detect_public(vol) == 0
+            t1 = time.time()
+            assert p.describe() == 0
+            t2 = time.time()
+            nkp = len(p.keypoints()["strength"])
+            p.close()
+            return dict(value=round(budget_n ** 3 / 1e6 / (t2 - t0), 4), unit="Mvoxel/s",
+                        cores=threads, kind="reference",
+                        sample="%d^3 lattice volume (1/%d of the workload's voxels), unmodified "
+                               "reference libsift3D (OpenMP): detect %.2f s + describe %.2f s, "
+                               "%d keypoints" % (budget_n, (512 // budget_n) ** 3, t1 - t0,
+                                                 t2 - t1, nkp))
+        except Exception as e:  # the reference build did not load on this host
+            sys.stderr.write("cpu_baseline: reference unavailable (%s), using the port\n" % e)
+    o = so.Oracle()
+    t0 = time.time()
+    assert o.detect(vol) == 0
+    t1 = time.time()
+    assert o.describe() == 0
+    t2 = time.time()
+    return dict(value=round(budget_n ** 3 / 1e6 / (t2 - t0), 4), unit="Mvoxel/s", cores=threads,
+                kind="port",
+                sample="%d^3 lattice volume, oracle restatement (OpenMP): detect %.2f s + describe "
+                       "%.2f s, %d keypoints" % (budget_n, t1 - t0, t2 - t1, len(o.keypoints())))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=512, help="edge of the (per-GPU) volume")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-micro", action="store_true", help="skip the per-kernel microbench")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sift3d_amd import api, hip
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+    if not torch.cuda.is_available() or not api.device_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU path to measure")
+    torch.cuda.set_device(local_rank)
+    hip.lib().sift3d_hip_set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = a.size
+    if world == 1:
+        vol = torch.empty((n, n, n), device="cuda")
+        hip.synth_lattice(vol, 0, 11)
+        torch.cuda.synchronize()
+        det = api.Detector()
+        kp, desc = api.KeypointStore(), api.DescriptorStore()
+
+        def step():
+            rc = det.detect_keypoints_device(vol.data_ptr(), n, n, n, kp)
+            assert rc == 0, "detect failed"
+            rc = det.extract_descriptors(kp, desc)
+            assert rc == 0, "describe failed"
+
+        voxels_per_step = n ** 3
+        stats = lambda: dict(candidates=det.num_candidates(), keypoints=len(kp),  # noqa: E731
+                             stage_s={k: round(v, 6) for k, v in det.timings().items()})
+        pyr_time = lambda: det.timings()["gauss_dev"]  # noqa: E731
+    else:
+        from sift3d_amd import sharded
+        job = sharded.ShardedSift3D(n, n, n * world, dist.group.WORLD)
+        job.synth(seed=11)
+        step = job.step
+        voxels_per_step = n ** 3 * world
+        stats = job.stats
+        pyr_time = job.pyramid_seconds
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pyr = []
+    for _ in range(a.steps):
+        step()
+        pyr.append(pyr_time())
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * dt / a.steps
+    value = voxels_per_step / 1e6 / (dt / a.steps)
+    out = {
+        "metric": "Mvoxel/s detect+describe (float32 volume resident in HBM)",
+        "value": round(value, 2), "unit": "Mvoxel/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%dx%dx%d float32 lattice-blob volume%s, detect+describe, default "
+                               "parameters (sigma0 1.6, sigma_n 1.15, 3 levels/octave)"
+                               % (n, n, n * world, "" if world == 1 else
+                                  " as %d Z-slabs of %d planes" % (world, n)),
+                   "parallelism": "single GPU" if world == 1 else "z-slab x%d" % world},
+    }
+    out.update(stats())
+    # pyramid roofline (whole Gaussian pyramid build, per GPU)
+    pbytes = pyramid_algorithmic_bytes(n, n, n)
+    pt = float(np.median(pyr)) if pyr and pyr[0] else None
+    pyramid = None
+    if pt:
+        ach = pbytes / 1e9 / pt
+        pyramid = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_GB": round(pbytes / 1e9, 3),
+                   "seconds": round(pt, 6)}
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))
+        except Exception:
+            traffic = None
+    if world == 1 and not a.no_micro:
+        kb = kernel_microbench(torch, hip, n)
+        dom = max(kb, key=lambda k: k["avg_ms"])
+        tr = None
+        if traffic and dom["kernel"] in traffic:
+            tr = traffic[dom["kernel"]]
+        out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"],
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": tr,
+                           "algorithmic_bytes_per_launch": int(8 * n ** 3),
+                           "avg_launch_ms": dom["avg_ms"], "pyramid": pyramid, "kernels": kb}
+    else:
+        out["roofline"] = dict(pyramid or {}, kernel="Gaussian pyramid (all k_fir_* launches)",
+                               traffic=None)
+    if not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

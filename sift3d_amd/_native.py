@@ -38,5 +38,5 @@ def load():
             import torch  # noqa: F401
         except Exception:
             pass
-        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _lib = C.CDLL(LIB_PATH)  # RTLD_LOCAL: the reference build in oracle/_ref exports the same 27 names
     return _lib

@@ -319,29 +319,60 @@ __global__ __launch_bounds__(256) void k_fir_literal(FirParams P, FirTaps T)
     const int y = (int)(r / P.nx);
     const int x = (int)(r % P.nx);
     const size_t idx = (size_t)z * plane + r;
-    const float *line;
-    size_t stride;
-    int p, n_loc, off, n_glob;
-    if (P.axis == 0) {
-        line = P.src + (size_t)z * plane + (size_t)y * P.nx;
-        stride = 1; p = x; n_loc = P.nx; off = 0; n_glob = P.nx;
-    } else if (P.axis == 1) {
-        line = P.src + (size_t)z * plane + x;
-        stride = P.nx; p = y; n_loc = P.ny; off = 0; n_glob = P.ny;
-    } else {
-        line = P.src + r;
-        stride = plane; p = z; n_loc = P.nz; off = P.off; n_glob = P.n_glob;
-    }
-    P.dst[idx] = fir_literal(line, stride, p + off, n_glob, off, n_loc, T.k, P.hw, P.uf, P.uhw);
+    // per-axis geometry by selects (no control flow): coordinate along the axis, stride,
+    // local extent; n_glob / off were resolved by the launcher
+    const int p = P.axis == 0 ? x : (P.axis == 1 ? y : z);
+    const size_t stride = P.axis == 0 ? (size_t)1 : (P.axis == 1 ? (size_t)P.nx : plane);
+    const int n_loc = P.axis == 0 ? P.nx : (P.axis == 1 ? P.ny : P.nz);
+    const float *line = P.src + (idx - (size_t)p * stride);
+    P.dst[idx] = fir_literal(line, stride, p + P.off, P.n_glob, P.off, n_loc, T.k, P.hw, P.uf,
+                             P.uhw);
 }
 
-// ---- x pass, unit factor 1 --------------------------------------------------------------
-// One wave per 512-output row segment.  The segment (+8-float halos) is staged in LDS with
-// coalesced 16-byte loads; each lane then pulls a 24-float window into registers and emits
-// 8 outputs.  With frac == 0 the reference's term tap*((1-0)*lo + 0*hi) equals tap*lo
-// exactly for finite data, so the interior is a plain FIR in the reference's tap order.
+// ---- unit factor 1 (octave 0): edges as a staging transformation ----------------------------
+// With uf == 1 every sample coordinate is an integer, and the reference's edge rules
+// (imutil.c:842-850) depend only on that integer i = x - d, not on (x, d) separately:
+//     i < 0          -> sample src[-i]                       (frac == 0)
+//     0 <= i < end   -> sample src[i]                        (frac == 0)
+//     i >= end = n-1 -> c' = 2*end - i - 0.1f, a fixed lerp of two samples near the end
+//                       (including i == end itself, quirk Q4)
+// and interior outputs never reach i >= end.  So the whole pass is  out[x] = sum_d k[d]*E[x-d]
+// over an EXTENDED line E with reflected samples on the low side and pre-interpolated
+// "virtual" samples v_m = w0_m*src[lo_m] + w1_m*src[lo_m+1] (m = i - end) on the high side.
+// tap*((1-frac)*lo + frac*hi) is evaluated exactly as written -- the inner expression is
+// v_m -- and for frac == 0 it equals tap*lo for finite data.  Requires n >= 2*hw + 2 (no
+// double mirroring); shorter axes take the literal kernel.  The (lo_m, w0_m, w1_m) table is
+// computed on the host with the reference's float expressions.
+struct EdgeTab {
+    int lo[9];
+    float w0[9], w1[9];
+};
+
+// E[i] for one line; i and the table are GLOBAL coordinates, the line pointer addresses local
+// index 0 and holds global indices [off, off + n_loc).
+__device__ __forceinline__ float ext_sample(const float *__restrict__ line, size_t stride, int i,
+                                            int end, int off, int n_loc, int hw,
+                                            const EdgeTab &E)
+{
+    if (i < 0) {
+        return -i <= hw ? line[(size_t)clampi(-i - off, 0, n_loc - 1) * stride] : 0.0f;
+    } else if (i >= end) {
+        const int m = i - end;
+        if (m > hw)
+            return 0.0f;
+        const int lo = E.lo[m];
+        const float a = line[(size_t)clampi(lo - off, 0, n_loc - 1) * stride];
+        const float b = line[(size_t)clampi(lo + 1 - off, 0, n_loc - 1) * stride];
+        return E.w0[m] * a + E.w1[m] * b;
+    }
+    return line[(size_t)clampi(i - off, 0, n_loc - 1) * stride];
+}
+
+// x pass: one wave per 512-output row segment.  The extended segment (+8-float halos) is
+// staged in LDS with coalesced 16-byte loads; each lane pulls a 24-float window into registers
+// and emits 8 outputs with the reference's tap order.  No edge code in the FIR itself.
 template <int HW>
-__global__ __launch_bounds__(256) void k_fir_x_u1(FirParams P, FirTaps T)
+__global__ __launch_bounds__(256) void k_fir_x_u1(FirParams P, FirTaps T, EdgeTab E)
 {
     constexpr int RX = 8, SEG = 64 * RX, HALO = 8, L = SEG + 2 * HALO;
     static_assert(HW <= HALO, "halo too small");
@@ -351,7 +382,7 @@ __global__ __launch_bounds__(256) void k_fir_x_u1(FirParams P, FirTaps T)
     const int row = blockIdx.y * 4 + wave;
     const bool active = row < nrows;
     const int x0 = blockIdx.x * SEG;
-    const int nx = P.nx;
+    const int nx = P.nx, end = nx - 1;
     const size_t rowoff = active ? ((size_t)(P.z_lo + row / P.ny) * P.ny + (row % P.ny)) * nx : 0;
     const float *__restrict__ s = P.src + rowoff;
     float *__restrict__ d = P.dst + rowoff;
@@ -361,13 +392,13 @@ __global__ __launch_bounds__(256) void k_fir_x_u1(FirParams P, FirTaps T)
         for (int i = lane; i < L / 4; i += 64) {
             const int gx = x0 - HALO + 4 * i;
             float4 v;
-            if (vec_ok && gx >= 0 && gx + 3 < nx) {
+            if (vec_ok && gx >= 0 && gx + 3 < end) {
                 v = ld4(s + gx);
             } else {
-                v.x = (gx >= 0 && gx < nx) ? s[gx] : 0.0f;
-                v.y = (gx + 1 >= 0 && gx + 1 < nx) ? s[gx + 1] : 0.0f;
-                v.z = (gx + 2 >= 0 && gx + 2 < nx) ? s[gx + 2] : 0.0f;
-                v.w = (gx + 3 >= 0 && gx + 3 < nx) ? s[gx + 3] : 0.0f;
+                v.x = ext_sample(s, 1, gx, end, 0, nx, HW, E);
+                v.y = ext_sample(s, 1, gx + 1, end, 0, nx, HW, E);
+                v.z = ext_sample(s, 1, gx + 2, end, 0, nx, HW, E);
+                v.w = ext_sample(s, 1, gx + 3, end, 0, nx, HW, E);
             }
             *reinterpret_cast<float4 *>(&lds[wave][4 * i]) = v;
         }
@@ -390,17 +421,8 @@ __global__ __launch_bounds__(256) void k_fir_x_u1(FirParams P, FirTaps T)
         float acc = 0.0f;
 #pragma unroll
         for (int dd = -HW; dd <= HW; dd++)
-            acc += T.k[dd + HW] * w[HALO + r - dd];   // src index x - d
+            acc += T.k[dd + HW] * w[HALO + r - dd];   // E[x - d], d ascending
         o[r] = acc;
-    }
-    // boundary outputs: the literal mirror arithmetic, straight from global memory
-    if (xb < HW || xb + RX - 1 > nx - 2 - HW) {
-#pragma unroll
-        for (int r = 0; r < RX; r++) {
-            const int x = xb + r;
-            if (x < nx && (x < HW || x > nx - 2 - HW))
-                o[r] = fir_literal(s, 1, x, nx, 0, nx, T.k, HW, 1.0f, HW);
-        }
     }
     if (vec_ok && xb + RX <= nx) {
         st4(d + xb, make_float4(o[0], o[1], o[2], o[3]));
@@ -415,10 +437,10 @@ __global__ __launch_bounds__(256) void k_fir_x_u1(FirParams P, FirTaps T)
 
 // ---- y / z pass, unit factor 1 ----------------------------------------------------------
 // Each thread owns V adjacent x (one 16-byte quad for V=4) and sweeps `ts` outputs along
-// the strided axis, keeping the 2*HW+1 most recent input rows in a register ring: every
-// input is loaded once per thread, loads are coalesced along x, nothing is transposed.
-// Whether an output row is "interior" depends only on the sweep coordinate, which is
-// wave-uniform, so the mirror path costs no divergence.
+// the strided axis, keeping the 2*HW+1 most recent rows of the EXTENDED line in a register
+// ring: every input is loaded once per thread, loads are coalesced along x, nothing is
+// transposed.  Whether a ring row is plain, reflected or virtual depends only on the sweep
+// coordinate, which is wave-uniform, so the edge rows cost no divergence.
 template <int V> struct Vec;
 template <> struct Vec<4> {
     typedef float4 T;
@@ -429,6 +451,11 @@ template <> struct Vec<4> {
     {
         acc.x += k * v.x; acc.y += k * v.y; acc.z += k * v.z; acc.w += k * v.w;
     }
+    static __device__ __forceinline__ T lerp(float w0, const T &a, float w1, const T &b)
+    {
+        return make_float4(w0 * a.x + w1 * b.x, w0 * a.y + w1 * b.y, w0 * a.z + w1 * b.z,
+                           w0 * a.w + w1 * b.w);
+    }
 };
 template <> struct Vec<1> {
     typedef float T;
@@ -436,6 +463,10 @@ template <> struct Vec<1> {
     static __device__ __forceinline__ void st(float *p, T v) { *p = v; }
     static __device__ __forceinline__ T zero() { return 0.0f; }
     static __device__ __forceinline__ void mac(T &acc, float k, const T &v) { acc += k * v; }
+    static __device__ __forceinline__ T lerp(float w0, const T &a, float w1, const T &b)
+    {
+        return w0 * a + w1 * b;
+    }
 };
 
 struct SweepGeom {
@@ -448,8 +479,28 @@ struct SweepGeom {
     int out_lo, out_hi; // local output range along the sweep axis
 };
 
+// row r (LOCAL index, may be outside [0, n_loc)) of the extended line
+template <int V>
+__device__ __forceinline__ typename Vec<V>::T ext_row(const float *__restrict__ s, size_t stride,
+                                                      int r, int off, int end, int nl1, int hw,
+                                                      const EdgeTab &E)
+{
+    const int i = r + off; // global, wave-uniform
+    if (i < 0) {
+        return Vec<V>::ld(s + (size_t)clampi(-i - off, 0, nl1) * stride);
+    } else if (i >= end) {
+        const int m = i - end;
+        if (m > hw)
+            return Vec<V>::zero();
+        const int lo = E.lo[m] - off;
+        return Vec<V>::lerp(E.w0[m], Vec<V>::ld(s + (size_t)clampi(lo, 0, nl1) * stride), E.w1[m],
+                            Vec<V>::ld(s + (size_t)clampi(lo + 1, 0, nl1) * stride));
+    }
+    return Vec<V>::ld(s + (size_t)clampi(r, 0, nl1) * stride);
+}
+
 template <int HW, int V>
-__global__ __launch_bounds__(256) void k_fir_sweep_u1(FirParams P, SweepGeom G, FirTaps T)
+__global__ __launch_bounds__(256) void k_fir_sweep_u1(FirParams P, SweepGeom G, FirTaps T, EdgeTab E)
 {
     typedef typename Vec<V>::T vec;
     constexpr int W = 2 * HW + 1;
@@ -463,33 +514,24 @@ __global__ __launch_bounds__(256) void k_fir_sweep_u1(FirParams P, SweepGeom G, 
     const float *__restrict__ s = P.src + base;
     float *__restrict__ d = P.dst + base;
     const int nl1 = G.n_loc - 1;
-    const int off = P.off, n_glob = P.n_glob;
+    const int off = P.off, end = P.n_glob - 1;
 
     vec ring[W];
 #pragma unroll
     for (int i = 0; i < 2 * HW; i++)
-        ring[i] = Vec<V>::ld(s + (size_t)clampi(p0 - HW + i, 0, nl1) * G.stride);
+        ring[i] = ext_row<V>(s, G.stride, p0 - HW + i, off, end, nl1, HW, E);
 
 #pragma unroll 1
     for (int p = p0; p < p1; p += W) {
 #pragma unroll
         for (int j = 0; j < W; j++) {
             const int q = p + j;
-            ring[(j + 2 * HW) % W] = Vec<V>::ld(s + (size_t)clampi(q + HW, 0, nl1) * G.stride);
+            ring[(j + 2 * HW) % W] = ext_row<V>(s, G.stride, q + HW, off, end, nl1, HW, E);
             if (q < p1) {
-                const int g = q + off;
                 vec acc = Vec<V>::zero();
-                if (g >= HW && g <= n_glob - 2 - HW) {
 #pragma unroll
-                    for (int dd = -HW; dd <= HW; dd++)
-                        Vec<V>::mac(acc, T.k[dd + HW], ring[(j + HW - dd) % W]);
-                } else {
-                    float *a = reinterpret_cast<float *>(&acc);
-#pragma unroll
-                    for (int v = 0; v < V; v++)
-                        a[v] = fir_literal(s + v, G.stride, g, n_glob, off, G.n_loc, T.k, HW,
-                                           1.0f, HW);
-                }
+                for (int dd = -HW; dd <= HW; dd++)
+                    Vec<V>::mac(acc, T.k[dd + HW], ring[(j + HW - dd) % W]);
                 Vec<V>::st(d + (size_t)q * G.stride, acc);
             }
         }
@@ -1196,23 +1238,41 @@ static int grid_for(size_t n, int per_thread)
 }
 
 template <int HW>
-static void launch_fir_x_u1(const FirParams &P, const FirTaps &T, hipStream_t st)
+static void launch_fir_x_u1(const FirParams &P, const FirTaps &T, const EdgeTab &E, hipStream_t st)
 {
     const int nrows = P.ny * (P.z_hi - P.z_lo);
     dim3 grid((P.nx + 511) / 512, (nrows + 3) / 4);
-    hipLaunchKernelGGL(k_fir_x_u1<HW>, grid, dim3(256), 0, st, P, T);
+    hipLaunchKernelGGL(k_fir_x_u1<HW>, grid, dim3(256), 0, st, P, T, E);
 }
 
 template <int HW>
-static void launch_fir_sweep_u1(const FirParams &P, const SweepGeom &G, const FirTaps &T, int V,
-                                hipStream_t st)
+static void launch_fir_sweep_u1(const FirParams &P, const SweepGeom &G, const FirTaps &T,
+                                const EdgeTab &E, int V, hipStream_t st)
 {
     const int nseg = (G.out_hi - G.out_lo + P.ts - 1) / P.ts;
     dim3 grid((G.ncols + 255) / 256, nseg);
     if (V == 4)
-        hipLaunchKernelGGL((k_fir_sweep_u1<HW, 4>), grid, dim3(256), 0, st, P, G, T);
+        hipLaunchKernelGGL((k_fir_sweep_u1<HW, 4>), grid, dim3(256), 0, st, P, G, T, E);
     else
-        hipLaunchKernelGGL((k_fir_sweep_u1<HW, 1>), grid, dim3(256), 0, st, P, G, T);
+        hipLaunchKernelGGL((k_fir_sweep_u1<HW, 1>), grid, dim3(256), 0, st, P, G, T, E);
+}
+
+// High-edge table of the extended line (imutil.c:846-848 + :783-788), reference float ops.
+static EdgeTab edge_table(int n_glob, int hw)
+{
+    EdgeTab E;
+    memset(&E, 0, sizeof(E));
+    const int dim_end = n_glob - 1;
+    for (int m = 0; m <= hw && m < 9; m++) {
+        float c = (float)(dim_end + m);            // (float)x - d, an exact integer
+        c = 2.0f * (float)dim_end - c - 0.1f;      // conv_eps mirror
+        const int lo = (int)c;
+        const float frac = c - (float)lo;
+        E.lo[m] = lo;
+        E.w0[m] = 1.0f - frac;
+        E.w1[m] = frac;
+    }
+    return E;
 }
 
 // device copies of the dyadic tap tables, keyed by (taps, uf); tiny LRU
@@ -1354,29 +1414,31 @@ int sift3d_hip_fir(const sift3d_hip_fir_args *a, void *stream)
         G.out_lo = a->z_lo; G.out_hi = a->z_hi;
     }
 
-    if (a->variant != 1 && P.uf == 1.0f && P.hw >= 1 && P.hw <= 8) {
-        // unit-spaced taps (octave 0): register-window kernels
+    if (a->variant != 1 && P.uf == 1.0f && P.hw >= 1 && P.hw <= 8 &&
+        P.n_glob >= 2 * P.hw + 2 && P.n_glob < (1 << 22)) {
+        // unit-spaced taps (octave 0): extended-line register-window kernels
+        const EdgeTab E = edge_table(P.n_glob, P.hw);
         if (a->axis == 0) {
             switch (P.hw) {
-            case 1: launch_fir_x_u1<1>(P, T, st); break;
-            case 2: launch_fir_x_u1<2>(P, T, st); break;
-            case 3: launch_fir_x_u1<3>(P, T, st); break;
-            case 4: launch_fir_x_u1<4>(P, T, st); break;
-            case 5: launch_fir_x_u1<5>(P, T, st); break;
-            case 6: launch_fir_x_u1<6>(P, T, st); break;
-            case 7: launch_fir_x_u1<7>(P, T, st); break;
-            default: launch_fir_x_u1<8>(P, T, st); break;
+            case 1: launch_fir_x_u1<1>(P, T, E, st); break;
+            case 2: launch_fir_x_u1<2>(P, T, E, st); break;
+            case 3: launch_fir_x_u1<3>(P, T, E, st); break;
+            case 4: launch_fir_x_u1<4>(P, T, E, st); break;
+            case 5: launch_fir_x_u1<5>(P, T, E, st); break;
+            case 6: launch_fir_x_u1<6>(P, T, E, st); break;
+            case 7: launch_fir_x_u1<7>(P, T, E, st); break;
+            default: launch_fir_x_u1<8>(P, T, E, st); break;
             }
         } else {
             switch (P.hw) {
-            case 1: launch_fir_sweep_u1<1>(P, G, T, V, st); break;
-            case 2: launch_fir_sweep_u1<2>(P, G, T, V, st); break;
-            case 3: launch_fir_sweep_u1<3>(P, G, T, V, st); break;
-            case 4: launch_fir_sweep_u1<4>(P, G, T, V, st); break;
-            case 5: launch_fir_sweep_u1<5>(P, G, T, V, st); break;
-            case 6: launch_fir_sweep_u1<6>(P, G, T, V, st); break;
-            case 7: launch_fir_sweep_u1<7>(P, G, T, V, st); break;
-            default: launch_fir_sweep_u1<8>(P, G, T, V, st); break;
+            case 1: launch_fir_sweep_u1<1>(P, G, T, E, V, st); break;
+            case 2: launch_fir_sweep_u1<2>(P, G, T, E, V, st); break;
+            case 3: launch_fir_sweep_u1<3>(P, G, T, E, V, st); break;
+            case 4: launch_fir_sweep_u1<4>(P, G, T, E, V, st); break;
+            case 5: launch_fir_sweep_u1<5>(P, G, T, E, V, st); break;
+            case 6: launch_fir_sweep_u1<6>(P, G, T, E, V, st); break;
+            case 7: launch_fir_sweep_u1<7>(P, G, T, E, V, st); break;
+            default: launch_fir_sweep_u1<8>(P, G, T, E, V, st); break;
             }
         }
     } else if (a->variant != 1 && dyadic && P.hw < 1024) {

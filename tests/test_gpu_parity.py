@@ -77,8 +77,14 @@ def test_device_eigen3_matches_host(gpu):
 # 1-D FIR stage: every kernel variant vs the reference's golden outputs and the oracle
 # ----------------------------------------------------------------------------------------
 def _fir_gpu(hip, torch, vol, taps, axis, uf, variant=0, **kw):
-    src = torch.from_numpy(np.ascontiguousarray(vol)).cuda()
-    dst = torch.full_like(src, float("nan"))
+    """Runs one pass with the source embedded between NaN guard bands: any read outside the
+    volume (even one with weight 0) poisons the output."""
+    vol = np.ascontiguousarray(vol, np.float32)
+    guard = 4096
+    big = torch.full((vol.size + 2 * guard,), float("nan"), device="cuda")
+    src = big[guard:guard + vol.size].view(vol.shape)
+    src.copy_(torch.from_numpy(vol))
+    dst = torch.full(vol.shape, float("nan"), device="cuda")
     hip.fir(src, dst, axis, taps, unit_factor=uf, variant=variant, **kw)
     torch.cuda.synchronize()
     return dst.cpu().numpy()
@@ -339,9 +345,11 @@ def test_reuse_and_errors(gpu, oracle_mod):
     assert len(kp) == 0
     assert det.extract_descriptors(kp, desc) == -1            # zero keypoints (sift.c:1178)
     assert det.set_sigma_n(5.0) == -1                         # sigma_n too large for sigma0
+    assert det.set_num_kp_levels(2) == -1                     # 1.6*2^(-1/2) < sigma_n = 1.15
+    assert det.set_sigma_n(1.0) == 0
     assert det.set_num_kp_levels(2) == 0                      # reallocates with an image set
     vol = oracle_mod.synth_survey(32)
     assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
-    o = oracle_mod.Oracle(num_kp_levels=2)
+    o = oracle_mod.Oracle(sigma_n=1.0, num_kp_levels=2)
     o.detect(vol)
     np.testing.assert_array_equal(kp.to_mat_rm(), o.kp_mat())
