@@ -999,17 +999,25 @@ struct FaceRec {
 };
 static_assert(sizeof(FaceRec) == SIFT3D_HIP_FACE_FLOATS * 4, "face record layout");
 
-__constant__ FaceRec c_faces[20];
-__constant__ int c_face_idx[60];
+// per-face constants as the kernel wants them: e1, e2, t, q, e2.q (+3 pad) = 16 floats
+__constant__ float c_face16[20 * 16];
+__constant__ int c_face_idx[60];   // unswapped vertex ids of each face (bins, quirk Q1)
+__constant__ float c_verts[12 * 3];// unit vertices
+__constant__ int c_vert_faces[12 * 5]; // the five faces around each vertex, ascending
+
+constexpr int DQ = 128; // compaction queue length (power of two, >= 2 * 64)
 
 __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restrict__ levels,
                                                  const sift3d_hip_kp *__restrict__ kps, uint32_t n,
-                                                 float *__restrict__ out)
+                                                 float *__restrict__ out, int ablate)
 {
     __shared__ float hist[768];
+    __shared__ __attribute__((aligned(16))) float sface[20 * 16];
     __shared__ float mw[8][65];   // mag * trilinear weight of the eight cells
     __shared__ float bw[3][65];   // barycentric weights
-    __shared__ int meta[64];      // ix | iy<<2 | iz<<4 | face<<6
+    __shared__ int meta[64];      // ix | iy<<2 | iz<<4 | bin0<<6 | bin1<<10 | bin2<<14
+    __shared__ int svf[12];       // the five faces around each vertex, 5 bits each
+    __shared__ int queue[DQ];     // xx | yy<<10 | zz<<20, window-relative, in scan order
     const uint32_t ki = blockIdx.x;
     if (ki >= n)
         return;
@@ -1018,6 +1026,12 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     const sift3d_hip_level L = levels[K.level];
     for (int i = lane; i < 768; i += 64)
         hist[i] = 0.0f;
+    for (int i = lane; i < 320; i += 64)
+        sface[i] = c_face16[i];
+    if (lane < 12)
+        svf[lane] = c_vert_faces[lane * 5] | (c_vert_faces[lane * 5 + 1] << 5) |
+                    (c_vert_faces[lane * 5 + 2] << 10) | (c_vert_faces[lane * 5 + 3] << 15) |
+                    (c_vert_faces[lane * 5 + 4] << 20);
 
     const float sigma = (float)(K.sd * 7.071067812);                  // sift.c:1453
     const float rad = (float)(2.0 * (double)sigma);                   // sift.c:1454
@@ -1034,105 +1048,182 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     bounds_f(K.cz, rad, L.uz, L.nz_glob, B.zs, B.ze);
     const int bx = B.xe - B.xs + 1, by = B.ye - B.ys + 1;
     const int npl = bx > 0 && by > 0 ? bx * by : 0;
-    // lanes 0..23 of phase B
-    const int pc = lane / 3, pj = lane - 3 * pc;       // cell corner, face vertex
+    // phase B roles: lanes 0..23 commit the first voxel of a pair, lanes 32..55 the second;
+    // each committer lane is one (trilinear cell corner, face vertex) pair
+    const int half = lane >> 5, l5 = lane & 31;
+    const int pc = l5 / 3, pj = l5 - 3 * pc;
     const int pdx = (pc >> 2) & 1, pdy = (pc >> 1) & 1, pdz = pc & 1;
+    const bool committer = l5 < 24;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     __syncthreads();
 
-    for (int z = B.zs; z <= B.ze; z++) {
+    uint32_t qhead = 0, qtail = 0; // wave-uniform
+
+    // Window voxel -> (window test, spatial bins).  Same float expressions in the scan and
+    // in the batch, so both see identical values.
+    auto window = [&](int x, int y, int z, float &sq, float &vbx, float &vby, float &vbz) -> bool {
+        const float dx = ((float)x - K.cx) * L.ux;                 // sift.c:102-104
+        const float dy = ((float)y - K.cy) * L.uy;
         const float dz = ((float)z - K.cz) * L.uz;
+        sq = dx * dx + dy * dy + dz * dz;
+        if (sq > rad2)                                             // sift.c:106 (float)
+            return false;
+        // vkp = Rt * vim (immacros.h:328-340)
+        const float kx = R[0] * dx + R[3] * dy + R[6] * dz;
+        const float ky = R[1] * dx + R[4] * dy + R[7] * dz;
+        const float kz = R[2] * dx + R[5] * dy + R[8] * dz;
+        vbx = (kx + half_w) * bin_f;                               // sift.c:1483-1485
+        vby = (ky + half_w) * bin_f;
+        vbz = (kz + half_w) * bin_f;
+        return !(vbx < 0 || vby < 0 || vbz < 0 || vbx >= 4.0f || vby >= 4.0f ||
+                 vbz >= 4.0f);                                     // sift.c:1488-1492
+    };
+
+    // One batch: the next `cnt` (<= 64) queued voxels, in scan order.
+    auto batch = [&](int cnt) {
+        bool ok = false;
+        if (ablate & 2) return;
+        if (lane < cnt) {
+            const int pk = queue[(qhead + lane) & (DQ - 1)];
+            const int x = B.xs + (pk & 1023), y = B.ys + ((pk >> 10) & 1023), z = B.zs + (pk >> 20);
+            float sq, vbx, vby, vbz;
+            window(x, y, z, sq, vbx, vby, vbz);
+            float gx, gy, gz;
+            grad_iso(L, x, y, z - L.z_off, gx, gy, gz);
+            const float w = s3d_expf(-0.5f * sq / sig2);           // sift.c:1498
+            gx = gx * w; gy = gy * w; gz = gz * w;
+            const float rx = R[0] * gx + R[3] * gy + R[6] * gz;    // sift.c:1502
+            const float ry = R[1] * gx + R[4] * gy + R[7] * gz;
+            const float rz = R[2] * gx + R[5] * gy + R[8] * gz;
+            const float m2 = rx * rx + ry * ry + rz * rz;
+            if (!(m2 < 1.1920928955078125e-06f)) {                 // sift.c:1264
+                // icos_hist_bin (sift.c:1268-1286): the first face in table order whose
+                // barycentrics are >= -eps wins.  Every face that can pass contains the
+                // icosahedron vertex nearest to the ray (its Voronoi cell is made of thirds
+                // of its five faces, and eps << the cell margins), so only those five are
+                // evaluated -- in ascending face order, with cart2bary's arithmetic.
+                int vs = 0;
+                float best = rx * c_verts[0] + ry * c_verts[1] + rz * c_verts[2];
+#pragma unroll
+                for (int v = 1; v < 12; v++) {
+                    const float dp = rx * c_verts[3 * v] + ry * c_verts[3 * v + 1] + rz * c_verts[3 * v + 2];
+                    if (dp > best) { best = dp; vs = v; }
+                }
+                int face = -1;
+                float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+                const int five = svf[vs];
+#pragma unroll 1
+                for (int k = 0; k < 5; k++) {
+                    const int f = (five >> (5 * k)) & 31;
+                    const float4 A0 = *reinterpret_cast<const float4 *>(&sface[f * 16]);
+                    const float4 A1 = *reinterpret_cast<const float4 *>(&sface[f * 16 + 4]);
+                    const float4 A2 = *reinterpret_cast<const float4 *>(&sface[f * 16 + 8]);
+                    const float4 A3 = *reinterpret_cast<const float4 *>(&sface[f * 16 + 12]);
+                    // e1 = A0.xyz, e2 = (A0.w, A1.x, A1.y), t = (A1.z, A1.w, A2.x),
+                    // q = (A2.y, A2.z, A2.w), e2.q = A3.x
+                    const float px = ry * A1.y - rz * A1.x;        // p = g x e2, sift.c:278
+                    const float py = rz * A0.w - rx * A1.y;
+                    const float pz = rx * A1.x - ry * A0.w;
+                    const float det = A0.x * px + A0.y * py + A0.z * pz;
+                    if (fabsf(det) < 1.1920928955078125e-06f)      // sift.c:282
+                        continue;
+                    const float di = 1.0f / det;
+                    const float yb = di * (A1.z * px + A1.w * py + A2.x * pz);
+                    const float zb = di * (rx * A2.y + ry * A2.z + rz * A2.w);
+                    const float xb = 1.0f - yb - zb;
+                    const float kk = A3.x * di;
+                    if (xb < -1.1920928955078125e-06f || yb < -1.1920928955078125e-06f ||
+                        zb < -1.1920928955078125e-06f || kk < 0)   // sift.c:1277-1279
+                        continue;
+                    face = f; b0 = xb; b1 = yb; b2 = zb;
+                    break;
+                }
+                if (face >= 0) {
+                    ok = true;
+                    const float mag = sqrtf(m2);                   // sift.c:1331
+                    const float fx = vbx - floorf(vbx);            // sift.c:1318-1320
+                    const float fy = vby - floorf(vby);
+                    const float fz = vbz - floorf(vbz);
+                    const float ax[2] = { 1.0f - fx, fx }, ay[2] = { 1.0f - fy, fy },
+                                az[2] = { 1.0f - fz, fz };
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        // weight = wx * wy * wz (sift.c:1361-1363); value = mag * weight * bary
+                        const float wt = ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1];
+                        mw[c][lane] = mag * wt;
+                    }
+                    bw[0][lane] = b0; bw[1][lane] = b1; bw[2][lane] = b2;
+                    // bins are addressed through the UNSWAPPED idx[] of the face (quirk Q1)
+                    meta[lane] = (int)vbx | ((int)vby << 2) | ((int)vbz << 4) |
+                                 (c_face_idx[face * 3] << 6) | (c_face_idx[face * 3 + 1] << 10) |
+                                 (c_face_idx[face * 3 + 2] << 14);
+                }
+            }
+        }
+        unsigned long long m = __ballot(ok);
+        if (ablate & 1) m = 0;
+        __syncthreads();
+        // Ordered commit, two voxels per iteration.  24 lanes per voxel (8 cells x 3 face
+        // vertices) each own one distinct histogram bin, so a voxel's 24 adds are ONE plain LDS
+        // read-modify-write; the first voxel's RMW is issued before the second's and a wave's
+        // DS operations execute in issue order, so every bin receives its contributions in the
+        // reference's voxel order (sift.c:1340-1373) and the float sums are bit-identical.
+        // (LDS float atomics would also be ordered but retire < 1 lane-add/clk/CU.)
+        while (m) {
+            const int va = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int vb2 = m ? __ffsll((long long)m) - 1 : -1;
+            m &= m - 1;
+            const int v = half ? vb2 : va;
+            float val = 0.0f;
+            int addr = -1;
+            if (committer && v >= 0) {
+                const int mt = meta[v];
+                const int cxx = (mt & 3) + pdx, cyy = ((mt >> 2) & 3) + pdy,
+                          czz = ((mt >> 4) & 3) + pdz;
+                if (cxx < 4 && cyy < 4 && czz < 4) {                          // sift.c:1349-1352
+                    addr = (cxx + 4 * cyy + 16 * czz) * 12 + ((mt >> (6 + 4 * pj)) & 15);
+                    val = mw[pc][v] * bw[pj][v];                              // sift.c:1371-1373
+                }
+            }
+            if (half == 0 && addr >= 0)
+                hist[addr] = hist[addr] + val;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (half == 1 && addr >= 0)
+                hist[addr] = hist[addr] + val;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+    };
+
+    for (int z = B.zs; z <= B.ze; z++) {
         for (int c0 = 0; c0 < npl; c0 += 64) {
             const int i = c0 + lane;
-            bool ok = false;
+            bool in = false;
+            int pk = 0;
             if (i < npl) {
                 const int yy = i / bx, xx = i - yy * bx;
-                const int x = B.xs + xx, y = B.ys + yy;
-                const float dx = ((float)x - K.cx) * L.ux;
-                const float dy = ((float)y - K.cy) * L.uy;
-                const float sq = dx * dx + dy * dy + dz * dz;
-                if (!(sq > rad2)) {                                        // sift.c:106 (float)
-                    // vkp = Rt * vim (immacros.h:328-340)
-                    const float kx = R[0] * dx + R[3] * dy + R[6] * dz;
-                    const float ky = R[1] * dx + R[4] * dy + R[7] * dz;
-                    const float kz = R[2] * dx + R[5] * dy + R[8] * dz;
-                    const float vbx = (kx + half_w) * bin_f;               // sift.c:1483-1485
-                    const float vby = (ky + half_w) * bin_f;
-                    const float vbz = (kz + half_w) * bin_f;
-                    if (!(vbx < 0 || vby < 0 || vbz < 0 || vbx >= 4.0f || vby >= 4.0f ||
-                          vbz >= 4.0f)) {                                  // sift.c:1488-1492
-                        float gx, gy, gz;
-                        grad_iso(L, x, y, z - L.z_off, gx, gy, gz);
-                        const float w = s3d_expf(-0.5f * sq / sig2);       // sift.c:1498
-                        gx = gx * w; gy = gy * w; gz = gz * w;
-                        const float rx = R[0] * gx + R[3] * gy + R[6] * gz; // sift.c:1502
-                        const float ry = R[1] * gx + R[4] * gy + R[7] * gz;
-                        const float rz = R[2] * gx + R[5] * gy + R[8] * gz;
-                        const float m2 = rx * rx + ry * ry + rz * rz;
-                        if (!(m2 < 1.1920928955078125e-06f)) {             // sift.c:1264
-                            // icos_hist_bin (sift.c:1268-1286) over cart2bary (sift.c:268-297)
-                            int face = -1;
-                            float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-                            for (int f = 0; f < 20; f++) {
-                                const FaceRec &F = c_faces[f];
-                                const float px = ry * F.e2[2] - rz * F.e2[1];
-                                const float py = rz * F.e2[0] - rx * F.e2[2];
-                                const float pz = rx * F.e2[1] - ry * F.e2[0];
-                                const float det = F.e1[0] * px + F.e1[1] * py + F.e1[2] * pz;
-                                if (fabsf(det) < 1.1920928955078125e-06f)   // sift.c:282
-                                    continue;
-                                const float di = 1.0f / det;
-                                const float yb = di * (F.t[0] * px + F.t[1] * py + F.t[2] * pz);
-                                const float zb = di * (rx * F.q[0] + ry * F.q[1] + rz * F.q[2]);
-                                const float xb = 1.0f - yb - zb;
-                                const float kk = F.e2q * di;
-                                if (xb < -1.1920928955078125e-06f || yb < -1.1920928955078125e-06f ||
-                                    zb < -1.1920928955078125e-06f || kk < 0)  // sift.c:1277-1279
-                                    continue;
-                                face = f; b0 = xb; b1 = yb; b2 = zb;
-                                break;
-                            }
-                            if (face >= 0) {
-                                ok = true;
-                                const float mag = sqrtf(m2);                // sift.c:1331
-                                const float fx = vbx - floorf(vbx);         // sift.c:1318-1320
-                                const float fy = vby - floorf(vby);
-                                const float fz = vbz - floorf(vbz);
-                                const float ax[2] = { 1.0f - fx, fx }, ay[2] = { 1.0f - fy, fy },
-                                            az[2] = { 1.0f - fz, fz };
-#pragma unroll
-                                for (int c = 0; c < 8; c++) {
-                                    // weight = wx * wy * wz (sift.c:1361-1363), value = mag * weight * bary
-                                    const float wt = ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1];
-                                    mw[c][lane] = mag * wt;
-                                }
-                                bw[0][lane] = b0; bw[1][lane] = b1; bw[2][lane] = b2;
-                                meta[lane] = (int)vbx | ((int)vby << 2) | ((int)vbz << 4) | (face << 6);
-                            }
-                        }
-                    }
-                }
+                float sq, vbx, vby, vbz;
+                in = window(B.xs + xx, B.ys + yy, z, sq, vbx, vby, vbz);
+                pk = xx | (yy << 10) | ((z - B.zs) << 20);
             }
-            unsigned long long m = __ballot(ok);
+            const unsigned long long m = __ballot(in);
             if (m == 0ull)
                 continue;
+            if (in)
+                queue[(qtail + (uint32_t)__popcll(m & lt_mask)) & (DQ - 1)] = pk;
+            qtail += (uint32_t)__popcll(m);
             __syncthreads();
-            while (m) {
-                const int v = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                if (lane < 24) {
-                    const int mt = meta[v];
-                    const int cxx = (mt & 3) + pdx, cyy = ((mt >> 2) & 3) + pdy,
-                              czz = ((mt >> 4) & 3) + pdz;
-                    if (cxx < 4 && cyy < 4 && czz < 4) {                     // sift.c:1349-1352
-                        const int bin = c_face_idx[(mt >> 6) * 3 + pj];       // unswapped idx[] (Q1)
-                        const float val = mw[pc][v] * bw[pj][v];              // sift.c:1371-1373
-                        atomicAdd(&hist[(cxx + 4 * cyy + 16 * czz) * 12 + bin], val);
-                    }
-                }
+            if (qtail - qhead >= 64) {
+                batch(64);
+                qhead += 64;
             }
-            __syncthreads();
         }
     }
+    if (qtail != qhead)
+        batch((int)(qtail - qhead));
     __syncthreads();
     // normalize_desc -> clamp -> normalize_desc (sift.c:1402-1429, 1514-1526).  The double
     // sum runs in element order on every lane (uniform), as in the reference.
@@ -1542,12 +1633,51 @@ int sift3d_hip_orient(const sift3d_hip_level *d_levels, const sift3d_hip_cand *d
 
 int sift3d_hip_set_mesh(const float *faces)
 {
-    int idx[60];
-    for (int f = 0; f < 20; f++)
+    int idx[60], vfaces[60], cnt[12];
+    float f16[20 * 16], verts[36];
+    memset(f16, 0, sizeof(f16));
+    memset(cnt, 0, sizeof(cnt));
+    memset(verts, 0, sizeof(verts));
+    for (int f = 0; f < 20; f++) {
+        const float *r = faces + f * SIFT3D_HIP_FACE_FLOATS;
         for (int j = 0; j < 3; j++)
-            idx[f * 3 + j] = (int)faces[f * SIFT3D_HIP_FACE_FLOATS + 16 + j];
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_faces), faces, sizeof(FaceRec) * 20));
+            idx[f * 3 + j] = (int)r[16 + j];
+        memcpy(f16 + f * 16, r + 3, sizeof(float) * 13); // e1, e2, t, q, e2.q
+        // unit vertices by id: the stored v0 is vertex idx[1] when the face was flipped for an
+        // outward normal and idx[0] otherwise (init_geometry, sift.c:237-241); e1 = v1 - v0 and
+        // e2 = v2 - v0 recover the other two exactly enough for a nearest-vertex search
+        for (int j = 0; j < 3; j++) {
+            const int id = idx[f * 3 + j];
+            if (id < 0 || id >= 12 || cnt[id] >= 5) {
+                snprintf(g_err, sizeof(g_err), "sift3d_hip_set_mesh: malformed face table");
+                return SIFT3D_FAILURE;
+            }
+            vfaces[id * 5 + cnt[id]++] = f; // faces visited in ascending order
+        }
+    }
+    // vertex coordinates: match each vertex id to one of the face's three stored corners by
+    // the golden-ratio pattern is unnecessary -- recompute them as init_geometry does
+    {
+        const float g = (float)1.6180339887;
+        const float vert[12][3] = { { 0, 1, g }, { 0, -1, g }, { 0, 1, -g }, { 0, -1, -g },
+                                    { 1, g, 0 }, { -1, g, 0 }, { 1, -g, 0 }, { -1, -g, 0 },
+                                    { g, 0, 1 }, { -g, 0, 1 }, { g, 0, -1 }, { -g, 0, -1 } };
+        for (int v = 0; v < 12; v++) {
+            const float mag = sqrtf(vert[v][0] * vert[v][0] + vert[v][1] * vert[v][1] +
+                                    vert[v][2] * vert[v][2]);
+            for (int k = 0; k < 3; k++)
+                verts[3 * v + k] = vert[v][k] * 1.0f / mag;
+        }
+    }
+    for (int v = 0; v < 12; v++)
+        if (cnt[v] != 5) {
+            snprintf(g_err, sizeof(g_err), "sift3d_hip_set_mesh: vertex %d has %d faces", v, cnt[v]);
+            return SIFT3D_FAILURE;
+        }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_face16), f16, sizeof(f16)));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_face_idx), idx, sizeof(idx)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_verts), verts, sizeof(verts)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_vert_faces), vfaces, sizeof(vfaces)));
     return SIFT3D_SUCCESS;
 }
 
@@ -1556,8 +1686,9 @@ int sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d
 {
     if (!n)
         return SIFT3D_SUCCESS;
+    static int ablate = getenv("SIFT3D_AMD_DESC_ABLATE") ? atoi(getenv("SIFT3D_AMD_DESC_ABLATE")) : 0;
     hipLaunchKernelGGL(k_describe, dim3(n), dim3(64), 0, (hipStream_t)stream, d_levels, d_kp, n,
-                       d_hist);
+                       d_hist, ablate);
     LAUNCH_CHECK();
     return SIFT3D_SUCCESS;
 }
