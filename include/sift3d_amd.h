@@ -79,6 +79,14 @@ sift3d_amd_keypoint_store_set(sift3d_keypoint_store *, int n, const int *os /*2n
 SIFT3D_AMD_API int
 sift3d_amd_descriptor_store_size(const sift3d_descriptor_store *);
 
+/* init_Gauss_filter (imutil.c:1267-1319) on the host: normalised taps for `sigma`.
+ * Returns the width (taps are written when width <= max_taps) or -1. */
+SIFT3D_AMD_API int sift3d_amd_gauss_filter(double sigma, float *taps, int max_taps);
+
+/* Uploads the icosahedron tables the descriptor kernel needs (done implicitly by the first
+ * detect); for callers that drive the sift3d_hip_* stages themselves. */
+SIFT3D_AMD_API int sift3d_amd_init(void);
+
 /* 1 when a usable HIP device is present. */
 SIFT3D_AMD_API int sift3d_amd_device_available(void);
 SIFT3D_AMD_API const char *sift3d_amd_version(void);

@@ -51,6 +51,9 @@ typedef struct {
     int nx, ny, nz;
     double ux, uy, uz;
     double s;
+    /* Z-slab views (orc_orient_slab / orc_describe_slab): data holds planes
+     * [z_off, z_off + nz) of a level with nz_glob planes.  0 / 0 = whole level. */
+    int z_off, nz_glob;
 } orc_level_t;
 
 typedef struct {
@@ -899,7 +902,7 @@ static void sphere_bounds(float c, double rad_d, float rad_f, int rad_is_double,
 static inline void grad_iso(const orc_level_t *im, int x, int y, int z, float *g)
 {
     const size_t ys = im->nx, zs = (size_t)im->nx * im->ny;
-    const float *p = im->data + x + ys * y + zs * z;
+    const float *p = im->data + x + ys * y + zs * (size_t)(z - im->z_off);
     g[0] = 0.5f * (p[1] - p[-1]);
     g[1] = 0.5f * (p[ys] - p[-(ptrdiff_t)ys]);
     g[2] = 0.5f * (p[zs] - p[-(ptrdiff_t)zs]);
@@ -923,7 +926,7 @@ static int orient_one(const orc_ctx *c, const orc_level_t *im, const float *ctr,
         return 1;
     sphere_bounds(ctr[0], win_radius, 0, 1, uxf, im->nx, &xs, &xe);
     sphere_bounds(ctr[1], win_radius, 0, 1, uyf, im->ny, &ys, &ye);
-    sphere_bounds(ctr[2], win_radius, 0, 1, uzf, im->nz, &zs, &ze);
+    sphere_bounds(ctr[2], win_radius, 0, 1, uzf, im->nz_glob ? im->nz_glob : im->nz, &zs, &ze);
     for (z = zs; z <= ze; z++)
         for (y = ys; y <= ye; y++)
             for (x = xs; x <= xe; x++) {
@@ -1066,7 +1069,7 @@ static void describe_one(const orc_ctx *c, const orc_level_t *im,
     memset(hist, 0, sizeof(float) * ORC_DESC_NUMEL);
     sphere_bounds(ctr[0], 0, win_radius, 0, uxf, im->nx, &xs, &xe);
     sphere_bounds(ctr[1], 0, win_radius, 0, uyf, im->ny, &ys, &ye);
-    sphere_bounds(ctr[2], 0, win_radius, 0, uzf, im->nz, &zs, &ze);
+    sphere_bounds(ctr[2], 0, win_radius, 0, uzf, im->nz_glob ? im->nz_glob : im->nz, &zs, &ze);
     for (z = zs; z <= ze; z++)
         for (y = ys; y <= ye; y++)
             for (x = xs; x <= xe; x++) {
@@ -1228,4 +1231,44 @@ void orc_mesh(const orc_ctx *c, float *v, int *idx)
                 v[(i * 3 + j) * 3 + k] = c->mesh[i].v[j][k];
             idx[i * 3 + j] = c->mesh[i].idx[j];
         }
+}
+
+/* ---- Z-slab views of the window stages (multi-GPU driver tests) ------------ */
+static void slab_level(orc_level_t *L, const float *data, int nx, int ny, int nz_loc,
+                       int z_off, int nz_glob, const double *units, double sd)
+{
+    memset(L, 0, sizeof(*L));
+    L->data = (float *)data;
+    L->nx = nx; L->ny = ny; L->nz = nz_loc;
+    L->ux = units[0]; L->uy = units[1]; L->uz = units[2];
+    L->s = sd;
+    L->z_off = z_off;
+    L->nz_glob = nz_glob;
+}
+
+int orc_orient_slab(const float *data, int nx, int ny, int nz_loc, int z_off, int nz_glob,
+                    const double *units, double sd, int x, int y, int z_glob,
+                    double corner_thresh, float *R)
+{
+    orc_ctx c;
+    orc_level_t L;
+    const float ctr[3] = { (float)(double)x, (float)(double)y, (float)(double)z_glob };
+    memset(&c, 0, sizeof(c));
+    c.corner_thresh = corner_thresh;
+    slab_level(&L, data, nx, ny, nz_loc, z_off, nz_glob, units, sd);
+    return !orient_one(&c, &L, ctr, k_ori_sig_fctr * sd, R); /* 1 = kept */
+}
+
+void orc_describe_slab(const float *data, int nx, int ny, int nz_loc, int z_off, int nz_glob,
+                       const double *units, const orc_keypoint *key, orc_descriptor *desc)
+{
+    static orc_ctx c;
+    static int init = 0;
+    orc_level_t L;
+    if (!init) {
+        build_mesh(c.mesh);
+        init = 1;
+    }
+    slab_level(&L, data, nx, ny, nz_loc, z_off, nz_glob, units, key->sd);
+    describe_one(&c, &L, key, desc);
 }

@@ -81,6 +81,8 @@ def lib():
         "sift3d_amd_version": (C.c_char_p, []),
         "sift3d_amd_synth_survey": (None, [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]),
         "sift3d_amd_synth_lattice": (None, [_f32p, C.c_int, C.c_int, C.c_int, C.c_uint64]),
+        "sift3d_amd_gauss_filter": (C.c_int, [C.c_double, _f32p, C.c_int]),
+        "sift3d_amd_init": (C.c_int, []),
         "sift3d_amd_host_expf": (None, [_f32p, _f32p, C.c_size_t]),
         "sift3d_amd_host_eigen3": (None, [_f64p, _f64p, _f64p]),
     }
@@ -326,3 +328,12 @@ def synth_lattice(n, seed=1):
     v = np.zeros((nz, ny, nx), np.float32)
     lib().sift3d_amd_synth_lattice(v, nx, ny, nz, seed)
     return v
+
+
+def gauss_filter(sigma):
+    """Normalised Gaussian taps exactly as the detector computes them (imutil.c:1267-1319)."""
+    taps = np.zeros(1024, np.float32)
+    w = lib().sift3d_amd_gauss_filter(float(sigma), taps, 1024)
+    if w < 1 or w > 1024:
+        raise ValueError("gauss_filter(%r)" % sigma)
+    return taps[:w].copy()

@@ -615,6 +615,20 @@ static int gauss_filter(filter_t *f, double sigma)
     return SIFT3D_SUCCESS;
 }
 
+/* Host filter bank entry for the multi-GPU driver (same code path as the detector's). */
+int sift3d_amd_gauss_filter(double sigma, float *taps, int max_taps)
+{
+    filter_t f;
+    int w;
+    if (gauss_filter(&f, sigma))
+        return -1;
+    w = f.width;
+    if (w <= max_taps)
+        memcpy(taps, f.taps, sizeof(float) * w);
+    free(f.taps);
+    return w;
+}
+
 /* make_gss, imutil.c:1360-1409 */
 static int build_filters(sift3d_detector *d)
 {
@@ -891,6 +905,17 @@ static int ensure_device(sift3d_detector *d)
     for (i = 0; i < 8; i++)
         if (!(d->ev[i] = sift3d_hip_event_create()))
             return SIFT3D_FAILURE;
+    return upload_mesh();
+}
+
+/* One-time device-side tables for callers of the stage ABI that do not go through a
+ * detector (the multi-GPU driver). */
+int sift3d_amd_init(void)
+{
+    if (!sift3d_amd_device_available()) {
+        ERR("sift3d_amd: no HIP device is available; this library has no CPU path \n");
+        return SIFT3D_FAILURE;
+    }
     return upload_mesh();
 }
 

@@ -142,3 +142,68 @@ def synth_lattice(dst, z_off=0, seed=1):
     _check(lib().sift3d_hip_synth_lattice(dst.data_ptr(), nx, ny, nz, z_off, seed, current_stream()),
            "sift3d_hip_synth_lattice")
     return dst
+
+
+def level_table(levels):
+    """levels: list of dicts(data=tensor, off, nz_glob, units, octave, sd) -> device table
+    (torch uint8 tensor) + the numpy mirror."""
+    import torch
+    tab = np.zeros(len(levels), LEVEL_DTYPE)
+    for i, L in enumerate(levels):
+        t = L["data"]
+        tab[i] = (t.data_ptr(), t.shape[2], t.shape[1], t.shape[0], L["off"], L["nz_glob"],
+                  np.float32(L["units"][0]), np.float32(L["units"][1]), np.float32(L["units"][2]),
+                  L["octave"], L["sd"])
+    dev = torch.from_numpy(tab.view(np.uint8).copy()).cuda()
+    return dev, tab
+
+
+def extrema(levels, nx, ny, nz, peak_thresh, cap=1 << 18):
+    """levels: list of dict(prev, cur, next (tensors), absmax (1-elem tensor), z_lo, z_hi, tag).
+    Returns CAND_DTYPE records in the reference's scan order."""
+    import torch
+    L = lib()
+    arr = (ExtremaLevel * len(levels))()
+    for i, lv in enumerate(levels):
+        arr[i] = ExtremaLevel(lv["prev"].data_ptr(), lv["cur"].data_ptr(), lv["next"].data_ptr(),
+                              lv["absmax"].data_ptr(), lv["z_lo"], lv["z_hi"], lv["tag"])
+    wb = L.sift3d_hip_extrema_work_bytes(nx, ny, nz, len(levels))
+    work = torch.empty(wb, dtype=torch.uint8, device="cuda")
+    count = torch.zeros(1, dtype=torch.int32, device="cuda")
+    while True:
+        out = torch.empty(cap * CAND_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        count.zero_()
+        _check(L.sift3d_hip_extrema(arr, len(levels), nx, ny, nz, float(peak_thresh), out.data_ptr(),
+                                    cap, count.data_ptr(), work.data_ptr(), wb, current_stream()),
+               "sift3d_hip_extrema")
+        n = int(count.item())
+        if n <= cap:
+            break
+        cap = n + n // 4 + 1024
+    return out[:n * CAND_DTYPE.itemsize].cpu().numpy().view(CAND_DTYPE).copy()
+
+
+def orient(d_levels, cands, corner_thresh):
+    import torch
+    n = len(cands)
+    if n == 0:
+        return np.zeros((0, 9), np.float32), np.zeros(0, np.int32)
+    dc = torch.from_numpy(np.ascontiguousarray(cands).view(np.uint8)).cuda()
+    R = torch.empty((n, 9), dtype=torch.float32, device="cuda")
+    keep = torch.empty(n, dtype=torch.int32, device="cuda")
+    _check(lib().sift3d_hip_orient(d_levels.data_ptr(), dc.data_ptr(), n, float(corner_thresh),
+                                   R.data_ptr(), keep.data_ptr(), current_stream()),
+           "sift3d_hip_orient")
+    return R.cpu().numpy(), keep.cpu().numpy()
+
+
+def describe(d_levels, kps):
+    import torch
+    n = len(kps)
+    if n == 0:
+        return np.zeros((0, 768), np.float32)
+    dk = torch.from_numpy(np.ascontiguousarray(kps).view(np.uint8)).cuda()
+    hist = torch.empty((n, 768), dtype=torch.float32, device="cuda")
+    _check(lib().sift3d_hip_describe(d_levels.data_ptr(), dk.data_ptr(), n, hist.data_ptr(),
+                                     current_stream()), "sift3d_hip_describe")
+    return hist.cpu().numpy()

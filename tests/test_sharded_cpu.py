@@ -1,0 +1,108 @@
+"""CPU (not gpu): the Z-slab multi-GPU orchestration (sift3d_amd/sharded.py) with gloo,
+world_size 2 and 3, on the oracle compute backend (tests/cpu_backend.py).
+
+What is under test is the sharding logic itself: slab bounds and their 2^k alignment, the
+per-blur z-halo exchange, the max all-reduces, the window halos, the replicated coarse
+octaves, the all-gather-v and its global (o, s, z, y, x) order incl. the stale-strength
+quirk.  The result must equal the single-process oracle bit-for-bit.
+"""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, dims, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    import torch
+    import torch.distributed as dist
+    from oracle import sift3d_oracle as so
+    from sift3d_amd import sharded
+    from tests.cpu_backend import OracleBackend
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
+                            world_size=world)
+    try:
+        nx, ny, nz = dims
+        vol = so.synth_survey(dims, nblob=int(200 * nx * ny * nz / 64 ** 3))
+        job = sharded.ShardedSift3D(nx, ny, nz, dist.group.WORLD, backend=OracleBackend())
+        z0, z1 = job.in_own
+        job.set_local_volume(vol[z0:z1])
+        kp = job.detect()
+        idx, hist = job.describe()
+        mat = job.gather_descriptors()
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), kp=kp, idx=idx, mat=mat,
+                 ncand=job.ncand, o_shard=job.g.o_shard, bounds=np.array(job.g.b0),
+                 num_octaves=job.g.num_octaves)
+    finally:
+        dist.destroy_process_group()
+
+
+def _reference(dims):
+    from oracle import sift3d_oracle as so
+    nx, ny, nz = dims
+    vol = so.synth_survey(dims, nblob=int(200 * nx * ny * nz / 64 ** 3))
+    o = so.Oracle()
+    assert o.detect(vol) == 0 and o.describe() == 0
+    return o
+
+
+@pytest.mark.parametrize("world,dims", [(2, (40, 44, 200)), (3, (36, 40, 152)), (2, (24, 24, 40))])
+def test_sharded_equals_single(world, dims):
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), dims, d), nprocs=world, join=True)
+        res = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(world)]
+    o = _reference(dims)
+    ok = o.keypoints()
+    assert len(ok) > 5
+    want_mat = o.desc_mat()
+    covered = np.zeros(len(ok), int)
+    for r, g in enumerate(res):
+        kp = g["kp"]
+        assert int(g["ncand"]) == len(o.candidates())
+        assert len(kp) == len(ok)
+        for f in ("o", "s", "xd", "yd", "zd", "sd", "strength"):
+            np.testing.assert_array_equal(kp[f], ok[f], err_msg="rank %d field %s" % (r, f))
+        np.testing.assert_array_equal(kp["R"], ok["R"])
+        np.testing.assert_array_equal(g["mat"], want_mat)
+        covered[g["idx"]] += 1
+    # every keypoint is described by exactly one rank
+    np.testing.assert_array_equal(covered, 1)
+    if dims[2] >= 150:
+        assert int(res[0]["o_shard"]) >= 1           # really sharded, not just replicated
+        b = res[0]["bounds"]
+        assert all(v % (1 << int(res[0]["o_shard"])) == 0 for v in b[:-1])
+    else:
+        assert int(res[0]["o_shard"]) == 0           # tiny volume: replicated, work split only
+
+
+def test_geometry_alignment():
+    from sift3d_amd.sharded import Geometry, MIN_SLAB
+    g = Geometry(512, 512, 4096, 8)
+    assert g.num_octaves == 7 and g.o_shard == 4
+    assert g.b0 == [512 * r for r in range(9)]
+    for o in range(g.o_shard):
+        for r in range(8):
+            z0, z1 = g.own(o, r)
+            assert z0 % 2 == 0 and z1 - z0 >= MIN_SLAB
+    g = Geometry(1024, 1024, 1024, 8)                 # BASELINE configs[3]
+    assert g.num_octaves == 8 and g.o_shard == 2 and g.own(0, 3) == (384, 512)
+    g = Geometry(100, 90, 333, 4)
+    assert sum(g.own(0, r)[1] - g.own(0, r)[0] for r in range(4)) == 333
+    g1 = Geometry(64, 64, 64, 1)
+    assert g1.o_shard == 0 and g1.own(0, 0) == (0, 64)
