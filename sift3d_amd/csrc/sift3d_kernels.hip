@@ -19,7 +19,6 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
-#include <mutex>
 
 #pragma clang fp contract(off)
 
@@ -270,15 +269,20 @@ struct FirParams {
 // LOCAL index 0 of the 1-D line; g is the GLOBAL coordinate of the output.  Samples are
 // clamped into the local buffer for memory safety only (a correct call never needs it,
 // except for the weight-0 `hi` read one past the row -- SURVEY.md A.2).
-__device__ __forceinline__ float fir_literal(const float *__restrict__ line, size_t stride,
-                                             int g, int n_glob, int off, int n_loc,
-                                             const float *__restrict__ taps, int hw,
-                                             float uf, int uhw)
+template <int HWT>
+__device__ __forceinline__ float fir_literal_t(const float *__restrict__ line, size_t stride,
+                                               int g, int n_glob, int off, int n_loc,
+                                               const float *__restrict__ taps, int hw_rt,
+                                               float uf, int uhw)
 {
+    // HWT > 0: compile-time half width -> the tap loop is fully unrolled and its 2*(2*HWT+1)
+    // loads are issued back to back (a rolled loop serialises one memory latency per tap)
+    const int hw = HWT > 0 ? HWT : hw_rt;
     const int dim_end = n_glob - 1;                               // :753
     const bool interior = g >= uhw && g <= n_glob - 2 - uhw;      // :762-763, :829
     float acc = 0.0f;                                             // im_zero, :777
     float coord = (float)g;
+#pragma unroll
     for (int d = -hw; d <= hw; d++) {
         const float tap = taps[d + hw];
         const float step = (float)d * uf;                         // :808 / :837
@@ -304,6 +308,14 @@ __device__ __forceinline__ float fir_literal(const float *__restrict__ line, siz
             coord += step;                                        // :817
     }
     return acc;
+}
+
+__device__ __forceinline__ float fir_literal(const float *__restrict__ line, size_t stride,
+                                             int g, int n_glob, int off, int n_loc,
+                                             const float *__restrict__ taps, int hw,
+                                             float uf, int uhw)
+{
+    return fir_literal_t<0>(line, stride, g, n_glob, off, n_loc, taps, hw, uf, uhw);
 }
 
 // literal kernel: one thread per output voxel, any axis, any unit factor
@@ -389,49 +401,64 @@ __global__ __launch_bounds__(256) void k_fir_x_u1(FirParams P, FirTaps T, EdgeTa
     const bool vec_ok = (nx & 3) == 0 && ((((uintptr_t)P.src | (uintptr_t)P.dst) & 15) == 0);
 
     if (active) {
+        // bulk: plain samples (zero outside the row)
         for (int i = lane; i < L / 4; i += 64) {
             const int gx = x0 - HALO + 4 * i;
             float4 v;
-            if (vec_ok && gx >= 0 && gx + 3 < end) {
+            if (vec_ok && gx >= 0 && gx + 3 < nx) {
                 v = ld4(s + gx);
             } else {
-                v.x = ext_sample(s, 1, gx, end, 0, nx, HW, E);
-                v.y = ext_sample(s, 1, gx + 1, end, 0, nx, HW, E);
-                v.z = ext_sample(s, 1, gx + 2, end, 0, nx, HW, E);
-                v.w = ext_sample(s, 1, gx + 3, end, 0, nx, HW, E);
+                v.x = (gx >= 0 && gx < nx) ? s[gx] : 0.0f;
+                v.y = (gx + 1 >= 0 && gx + 1 < nx) ? s[gx + 1] : 0.0f;
+                v.z = (gx + 2 >= 0 && gx + 2 < nx) ? s[gx + 2] : 0.0f;
+                v.w = (gx + 3 >= 0 && gx + 3 < nx) ? s[gx + 3] : 0.0f;
             }
             *reinterpret_cast<float4 *>(&lds[wave][4 * i]) = v;
+        }
+        // edge samples of the extended line, one per lane (DS writes of a wave retire in
+        // order, so these overwrite the bulk values): E[-1..-8] and E[end..end+8]
+        if (lane < 17) {
+            const int gi = lane < 8 ? -1 - lane : end + (lane - 8);
+            const int pos = gi - (x0 - HALO);
+            if (pos >= 0 && pos < L)
+                lds[wave][pos] = ext_sample(s, 1, gi, end, 0, nx, HW, E);
         }
     }
     __syncthreads();
     if (!active)
         return;
-    const int xb = x0 + lane * RX; // first output of this lane
-    if (xb >= nx)
-        return;
-    float w[RX + 2 * HALO];
+    // Two groups of 4 consecutive outputs per lane, 256 apart: lane l owns x0 + 256 g + 4 l ..+3,
+    // so both the LDS window reads (16 B per lane, lane stride 16 B: conflict free) and the
+    // global stores (64 lanes x 16 B contiguous) are fully coalesced.
 #pragma unroll
-    for (int i = 0; i < (RX + 2 * HALO) / 4; i++) {
-        const float4 v = *reinterpret_cast<const float4 *>(&lds[wave][lane * RX + 4 * i]);
-        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-    }
-    float o[RX];
+    for (int grp = 0; grp < 2; grp++) {
+        const int lb = grp * 256 + lane * 4;       // offset of the first output in the segment
+        const int xb = x0 + lb;
+        if (xb >= nx)
+            continue;
+        float w[4 + 2 * HALO];
 #pragma unroll
-    for (int r = 0; r < RX; r++) {
-        float acc = 0.0f;
+        for (int i = 0; i < (4 + 2 * HALO) / 4; i++) {
+            const float4 v = *reinterpret_cast<const float4 *>(&lds[wave][lb + 4 * i]);
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+        float o[4];
 #pragma unroll
-        for (int dd = -HW; dd <= HW; dd++)
-            acc += T.k[dd + HW] * w[HALO + r - dd];   // E[x - d], d ascending
-        o[r] = acc;
-    }
-    if (vec_ok && xb + RX <= nx) {
-        st4(d + xb, make_float4(o[0], o[1], o[2], o[3]));
-        st4(d + xb + 4, make_float4(o[4], o[5], o[6], o[7]));
-    } else {
+        for (int r = 0; r < 4; r++) {
+            float acc = 0.0f;
 #pragma unroll
-        for (int r = 0; r < RX; r++)
-            if (xb + r < nx)
-                d[xb + r] = o[r];
+            for (int dd = -HW; dd <= HW; dd++)
+                acc += T.k[dd + HW] * w[HALO + r - dd];   // E[x - d], d ascending
+            o[r] = acc;
+        }
+        if (vec_ok && xb + 4 <= nx) {
+            st4(d + xb, make_float4(o[0], o[1], o[2], o[3]));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (xb + r < nx)
+                    d[xb + r] = o[r];
+        }
     }
 }
 
@@ -550,15 +577,10 @@ struct DyadTaps {
     int off[SIFT3D_HIP_MAX_TAPS];  // lo - g
 };
 
-template <int V>
-__global__ __launch_bounds__(256) void k_fir_sweep_dyad(FirParams P, SweepGeom G,
-                                                        const DyadTaps *__restrict__ Tp)
+template <int HW, int V>
+__global__ __launch_bounds__(256) void k_fir_sweep_dyad(FirParams P, SweepGeom G, DyadTaps T)
 {
     typedef typename Vec<V>::T vec;
-    __shared__ DyadTaps T;
-    for (int i = threadIdx.x; i < (int)(sizeof(DyadTaps) / 4); i += blockDim.x)
-        reinterpret_cast<int *>(&T)[i] = reinterpret_cast<const int *>(Tp)[i];
-    __syncthreads();
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= G.ncols)
         return;
@@ -569,9 +591,10 @@ __global__ __launch_bounds__(256) void k_fir_sweep_dyad(FirParams P, SweepGeom G
     float *__restrict__ d = P.dst + base;
     const int g = q + P.off;
     const int nl1 = G.n_loc - 1;
-    const int W = 2 * P.hw + 1;
+    const int W = HW > 0 ? 2 * HW + 1 : 2 * P.hw + 1;   // HW == 0: run-time width
     vec acc = Vec<V>::zero();
     if (g >= P.uhw && g <= P.n_glob - 2 - P.uhw) {
+#pragma unroll
         for (int t = 0; t < W; t++) {
             const int lo = clampi(q + T.off[t], 0, nl1);
             const int hi = clampi(q + T.off[t] + 1, 0, nl1);
@@ -589,19 +612,16 @@ __global__ __launch_bounds__(256) void k_fir_sweep_dyad(FirParams P, SweepGeom G
         float *cf = reinterpret_cast<float *>(&acc);
 #pragma unroll
         for (int v = 0; v < V; v++)
-            cf[v] = fir_literal(s + v, G.stride, g, P.n_glob, P.off, G.n_loc, T.k, P.hw, P.uf,
-                                P.uhw);
+            cf[v] = fir_literal_t<HW>(s + v, G.stride, g, P.n_glob, P.off, G.n_loc, T.k, P.hw, P.uf,
+                                      P.uhw);
     }
     Vec<V>::st(d + (size_t)q * G.stride, acc);
 }
 
-// x pass for dyadic unit factors: one thread per output voxel, taps from LDS
-__global__ __launch_bounds__(256) void k_fir_x_dyad(FirParams P, const DyadTaps *__restrict__ Tp)
+// x pass for dyadic unit factors: one thread per output voxel
+template <int HW>
+__global__ __launch_bounds__(256) void k_fir_x_dyad(FirParams P, DyadTaps T)
 {
-    __shared__ DyadTaps T;
-    for (int i = threadIdx.x; i < (int)(sizeof(DyadTaps) / 4); i += blockDim.x)
-        reinterpret_cast<int *>(&T)[i] = reinterpret_cast<const int *>(Tp)[i];
-    __syncthreads();
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= P.nx)
         return;
@@ -609,18 +629,180 @@ __global__ __launch_bounds__(256) void k_fir_x_dyad(FirParams P, const DyadTaps 
     const size_t rowoff = ((size_t)(P.z_lo + row / P.ny) * P.ny + (row % P.ny)) * P.nx;
     const float *__restrict__ s = P.src + rowoff;
     const int nl1 = P.nx - 1;
-    const int W = 2 * P.hw + 1;
+    const int W = HW > 0 ? 2 * HW + 1 : 2 * P.hw + 1;
     float acc = 0.0f;
     if (x >= P.uhw && x <= P.nx - 2 - P.uhw) {
+#pragma unroll
         for (int t = 0; t < W; t++) {
             const float a = s[clampi(x + T.off[t], 0, nl1)];
             const float b = s[clampi(x + T.off[t] + 1, 0, nl1)];
             acc += T.k[t] * (T.w0[t] * a + T.w1[t] * b);
         }
     } else {
-        acc = fir_literal(s, 1, x, P.nx, 0, P.nx, T.k, P.hw, P.uf, P.uhw);
+        acc = fir_literal_t<HW>(s, 1, x, P.nx, 0, P.nx, T.k, P.hw, P.uf, P.uhw);
     }
     P.dst[rowoff + x] = acc;
+}
+
+// ---- tap spacings 1/2 and 1/4 (octaves 1 and 2): register-resident source window -----------
+// For uf = 2^-S the interior sample of tap d sits at g + off_d + frac_d with the COMPILE-TIME
+// constants off_d = floor(-d / 2^S) and frac_d = (-d mod 2^S) / 2^S (exactly what the
+// reference's float expressions give, imutil.c:783-788, since g - d*uf is exact).  Source rows
+// g-R .. g+R+1 (R = ceil(HW / 2^S)) are kept in a register ring (y/z sweeps) or a register
+// window filled from LDS (x), so each input is loaded once per thread, and every term is the
+// literal tap*((1-frac)*lo + frac*hi) (tap*lo when frac == 0).  Outputs classified "boundary"
+// by the reference (g < uhw or g > n-2-uhw) take the literal mirror arithmetic: wave-uniform
+// rows in the sweeps; for the x pass a separate edge kernel overwrites the few columns.
+template <int S> __host__ __device__ constexpr int dy_off(int d) { return (-d) >> S; }
+template <int S> __host__ __device__ constexpr int dy_num(int d) { return (-d) - (((-d) >> S) << S); }
+
+template <int S, int V>
+__device__ __forceinline__ void dy_term(typename Vec<V>::T &acc, float k, int d,
+                                        const typename Vec<V>::T &a, const typename Vec<V>::T &b)
+{
+    const int num = (-d) - (((-d) >> S) << S);
+    if (num == 0) {
+        Vec<V>::mac(acc, k, a);
+    } else {
+        const float w1 = (float)num / (float)(1 << S), w0 = 1.0f - w1;
+        Vec<V>::mac(acc, k, Vec<V>::lerp(w0, a, w1, b));
+    }
+}
+
+template <int HW, int S, int V>
+__global__ __launch_bounds__(256) void k_fir_sweep_dy(FirParams P, SweepGeom G, FirTaps T)
+{
+    typedef typename Vec<V>::T vec;
+    constexpr int R = (HW + (1 << S) - 1) >> S;   // ceil(HW / 2^S)
+    constexpr int RW = 2 * R + 2;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= G.ncols)
+        return;
+    const int p0 = G.out_lo + blockIdx.y * P.ts;
+    const int p1 = min(p0 + P.ts, G.out_hi);
+    const size_t base = (size_t)(G.outer_lo + col / G.cols_inner) * G.outer_stride +
+                        (size_t)(col % G.cols_inner) * V;
+    const float *__restrict__ s = P.src + base;
+    float *__restrict__ d = P.dst + base;
+    const int nl1 = G.n_loc - 1;
+    const int off = P.off, n_glob = P.n_glob, uhw = P.uhw;
+
+    vec ring[RW];
+#pragma unroll
+    for (int i = 0; i < RW - 1; i++)
+        ring[i] = Vec<V>::ld(s + (size_t)clampi(p0 - R + i, 0, nl1) * G.stride);
+
+#pragma unroll 1
+    for (int p = p0; p < p1; p += RW) {
+#pragma unroll
+        for (int j = 0; j < RW; j++) {
+            const int q = p + j;
+            ring[(j + RW - 1) % RW] = Vec<V>::ld(s + (size_t)clampi(q + R + 1, 0, nl1) * G.stride);
+            if (q < p1) {
+                const int g = q + off;
+                vec acc = Vec<V>::zero();
+                if (g >= uhw && g <= n_glob - 2 - uhw) {
+#pragma unroll
+                    for (int dd = -HW; dd <= HW; dd++) {
+                        const int o = ((-dd) >> S);          // floor(-d / 2^S), compile time
+                        dy_term<S, V>(acc, T.k[dd + HW], dd, ring[(j + o + R + RW) % RW],
+                                      ring[(j + o + R + 1 + RW) % RW]);
+                    }
+                } else {
+                    float *a = reinterpret_cast<float *>(&acc);
+#pragma unroll
+                    for (int v = 0; v < V; v++)
+                        a[v] = fir_literal_t<HW>(s + v, G.stride, g, n_glob, off, G.n_loc, T.k, HW,
+                                                 P.uf, uhw);
+                }
+                Vec<V>::st(d + (size_t)q * G.stride, acc);
+            }
+        }
+    }
+}
+
+template <int HW, int S>
+__global__ __launch_bounds__(256) void k_fir_x_dy(FirParams P, FirTaps T)
+{
+    constexpr int RX = 8, SEG = 64 * RX, HALO = 8, L = SEG + 2 * HALO;
+    constexpr int R = (HW + (1 << S) - 1) >> S;
+    static_assert(R + 1 <= HALO, "halo too small");
+    __shared__ __attribute__((aligned(16))) float lds[4][L];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nrows = P.ny * (P.z_hi - P.z_lo);
+    const int row = blockIdx.y * 4 + wave;
+    const bool active = row < nrows;
+    const int x0 = blockIdx.x * SEG;
+    const int nx = P.nx;
+    const size_t rowoff = active ? ((size_t)(P.z_lo + row / P.ny) * P.ny + (row % P.ny)) * nx : 0;
+    const float *__restrict__ s = P.src + rowoff;
+    float *__restrict__ d = P.dst + rowoff;
+    const bool vec_ok = (nx & 3) == 0 && ((((uintptr_t)P.src | (uintptr_t)P.dst) & 15) == 0);
+    if (active) {
+        for (int i = lane; i < L / 4; i += 64) {
+            const int gx = x0 - HALO + 4 * i;
+            float4 v;
+            if (vec_ok && gx >= 0 && gx + 3 < nx) {
+                v = ld4(s + gx);
+            } else {
+                v.x = (gx >= 0 && gx < nx) ? s[gx] : 0.0f;
+                v.y = (gx + 1 >= 0 && gx + 1 < nx) ? s[gx + 1] : 0.0f;
+                v.z = (gx + 2 >= 0 && gx + 2 < nx) ? s[gx + 2] : 0.0f;
+                v.w = (gx + 3 >= 0 && gx + 3 < nx) ? s[gx + 3] : 0.0f;
+            }
+            *reinterpret_cast<float4 *>(&lds[wave][4 * i]) = v;
+        }
+    }
+    __syncthreads();
+    if (!active)
+        return;
+    const int xb = x0 + lane * RX;
+    if (xb >= nx)
+        return;
+    float w[RX + 2 * HALO];
+#pragma unroll
+    for (int i = 0; i < (RX + 2 * HALO) / 4; i++) {
+        const float4 v = *reinterpret_cast<const float4 *>(&lds[wave][lane * RX + 4 * i]);
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    float o[RX];
+#pragma unroll
+    for (int r = 0; r < RX; r++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int dd = -HW; dd <= HW; dd++) {
+            const int of = ((-dd) >> S);
+            dy_term<S, 1>(acc, T.k[dd + HW], dd, w[HALO + r + of], w[HALO + r + of + 1]);
+        }
+        o[r] = acc;   // boundary columns are rewritten by k_fir_x_edges
+    }
+    if (vec_ok && xb + RX <= nx) {
+        st4(d + xb, make_float4(o[0], o[1], o[2], o[3]));
+        st4(d + xb + 4, make_float4(o[4], o[5], o[6], o[7]));
+    } else {
+#pragma unroll
+        for (int r = 0; r < RX; r++)
+            if (xb + r < nx)
+                d[xb + r] = o[r];
+    }
+}
+
+// boundary columns of an x pass (x < uhw or x > nx-2-uhw): one thread per (row, column)
+template <int HW>
+__global__ __launch_bounds__(256) void k_fir_x_edges(FirParams P, FirTaps T)
+{
+    const int nedge = 2 * P.uhw + 1;               // uhw low + (uhw + 1) high columns
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nrows = (size_t)P.ny * (P.z_hi - P.z_lo);
+    if (i >= nrows * nedge)
+        return;
+    const size_t row = i / nedge;
+    const int e = (int)(i % nedge);
+    const int x = e < P.uhw ? e : P.nx - 1 - P.uhw + (e - P.uhw);
+    if (x < 0 || x >= P.nx || (x >= P.uhw && x <= P.nx - 2 - P.uhw))
+        return;
+    const size_t rowoff = ((size_t)P.z_lo * P.ny + row) * P.nx;
+    P.dst[rowoff + x] = fir_literal_t<HW>(P.src + rowoff, 1, x, P.nx, 0, P.nx, T.k, P.hw, P.uf, P.uhw);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1366,51 +1548,88 @@ static EdgeTab edge_table(int n_glob, int hw)
     return E;
 }
 
-// device copies of the dyadic tap tables, keyed by (taps, uf); tiny LRU
-struct DyadSlot {
-    DyadTaps host;
-    DyadTaps *dev;
-    int width;
-    float uf;
-    bool used;
-};
-static DyadSlot g_dyad[128];
-static std::mutex g_dyad_mu;
-static int g_dyad_next = 0;
-
-static const DyadTaps *dyad_table(const float *taps, int width, float uf, hipStream_t st)
+// per-tap (offset, 1-frac, frac) of a dyadic unit factor: the reference's float expressions
+// (imutil.c:783-788) evaluated at an index where g -+ hw*uf is exact
+static void dyad_table(DyadTaps &D, const float *taps, int width, float uf)
 {
     const int hw = width / 2;
-    std::lock_guard<std::mutex> lock(g_dyad_mu);
-    for (int i = 0; i < 128; i++)
-        if (g_dyad[i].used && g_dyad[i].width == width && g_dyad[i].uf == uf &&
-            memcmp(g_dyad[i].host.k, taps, sizeof(float) * width) == 0)
-            return g_dyad[i].dev;
-    DyadSlot &S = g_dyad[g_dyad_next];
-    g_dyad_next = (g_dyad_next + 1) % 128;
-    memset(&S.host, 0, sizeof(S.host));
+    memset(&D, 0, sizeof(D));
     for (int d = -hw; d <= hw; d++) {
-        // the reference's float expressions at an index where g -+ hw*uf is exact
         const int g0 = 1 << 10;
         const float c = (float)g0 - (float)d * uf;
         const int lo = (int)c;
         const float frac = c - (float)lo;
-        S.host.k[d + hw] = taps[d + hw];
-        S.host.w0[d + hw] = 1.0f - frac;
-        S.host.w1[d + hw] = frac;
-        S.host.off[d + hw] = lo - g0;
+        D.k[d + hw] = taps[d + hw];
+        D.w0[d + hw] = 1.0f - frac;
+        D.w1[d + hw] = frac;
+        D.off[d + hw] = lo - g0;
     }
-    if (!S.dev && hipMalloc((void **)&S.dev, sizeof(DyadTaps)) != hipSuccess)
-        return nullptr;
-    // synchronous w.r.t. the host buffer: the slot may be recycled later
-    if (hipMemcpyAsync(S.dev, &S.host, sizeof(DyadTaps), hipMemcpyHostToDevice, st) != hipSuccess)
-        return nullptr;
-    if (hipStreamSynchronize(st) != hipSuccess)
-        return nullptr;
-    S.width = width;
-    S.uf = uf;
-    S.used = true;
-    return S.dev;
+}
+
+template <int HW, int S>
+static void launch_fir_dy(const FirParams &P, const SweepGeom &G, const FirTaps &T, int V,
+                          hipStream_t st)
+{
+    if (P.axis == 0) {
+        const int nrows = P.ny * (P.z_hi - P.z_lo);
+        dim3 grid((P.nx + 511) / 512, (nrows + 3) / 4);
+        hipLaunchKernelGGL((k_fir_x_dy<HW, S>), grid, dim3(256), 0, st, P, T);
+        const size_t nedge = (size_t)nrows * (2 * P.uhw + 1);
+        hipLaunchKernelGGL(k_fir_x_edges<HW>, dim3((unsigned)((nedge + 255) / 256)), dim3(256), 0, st, P, T);
+    } else {
+        const int nseg = (G.out_hi - G.out_lo + P.ts - 1) / P.ts;
+        dim3 grid((G.ncols + 255) / 256, nseg);
+        hipLaunchKernelGGL((k_fir_sweep_dy<HW, S, 4>), grid, dim3(256), 0, st, P, G, T);
+    }
+}
+
+template <int HW>
+static void launch_fir_dyad_hw(const FirParams &P, const SweepGeom &G, const DyadTaps &dt, int V,
+                               hipStream_t st)
+{
+    if (P.axis == 0) {
+        dim3 grid((P.nx + 255) / 256, P.ny * (P.z_hi - P.z_lo));
+        hipLaunchKernelGGL(k_fir_x_dyad<HW>, grid, dim3(256), 0, st, P, dt);
+    } else {
+        dim3 grid((G.ncols + 255) / 256, G.out_hi - G.out_lo);
+        if (V == 4)
+            hipLaunchKernelGGL((k_fir_sweep_dyad<HW, 4>), grid, dim3(256), 0, st, P, G, dt);
+        else
+            hipLaunchKernelGGL((k_fir_sweep_dyad<HW, 1>), grid, dim3(256), 0, st, P, G, dt);
+    }
+}
+
+static void launch_fir_dyad_generic(const FirParams &P, const SweepGeom &G, const DyadTaps &dt,
+                                    int V, hipStream_t st)
+{
+    switch (P.hw) {
+    case 1: launch_fir_dyad_hw<1>(P, G, dt, V, st); break;
+    case 2: launch_fir_dyad_hw<2>(P, G, dt, V, st); break;
+    case 3: launch_fir_dyad_hw<3>(P, G, dt, V, st); break;
+    case 4: launch_fir_dyad_hw<4>(P, G, dt, V, st); break;
+    case 5: launch_fir_dyad_hw<5>(P, G, dt, V, st); break;
+    case 6: launch_fir_dyad_hw<6>(P, G, dt, V, st); break;
+    case 7: launch_fir_dyad_hw<7>(P, G, dt, V, st); break;
+    case 8: launch_fir_dyad_hw<8>(P, G, dt, V, st); break;
+    default: launch_fir_dyad_hw<0>(P, G, dt, V, st); break;
+    }
+}
+
+template <int S>
+static bool launch_fir_dy_hw(const FirParams &P, const SweepGeom &G, const FirTaps &T, int V,
+                             hipStream_t st)
+{
+    switch (P.hw) {
+    case 1: launch_fir_dy<1, S>(P, G, T, V, st); return true;
+    case 2: launch_fir_dy<2, S>(P, G, T, V, st); return true;
+    case 3: launch_fir_dy<3, S>(P, G, T, V, st); return true;
+    case 4: launch_fir_dy<4, S>(P, G, T, V, st); return true;
+    case 5: launch_fir_dy<5, S>(P, G, T, V, st); return true;
+    case 6: launch_fir_dy<6, S>(P, G, T, V, st); return true;
+    case 7: launch_fir_dy<7, S>(P, G, T, V, st); return true;
+    case 8: launch_fir_dy<8, S>(P, G, T, V, st); return true;
+    default: return false;
+    }
 }
 
 static bool is_dyadic(float uf, int *shift)
@@ -1505,6 +1724,19 @@ int sift3d_hip_fir(const sift3d_hip_fir_args *a, void *stream)
         G.out_lo = a->z_lo; G.out_hi = a->z_hi;
     }
 
+    if (a->axis != 0) {
+        // sweep segmentation: aim at >= 8 waves per SIMD (8192 waves) without letting the ring
+        // warm-up (2*hw extra rows per segment) dominate
+        const int n_out = G.out_hi - G.out_lo;
+        long want = (8192L * 64 + G.ncols - 1) / (G.ncols > 0 ? G.ncols : 1);
+        long cap = n_out / 16 > 1 ? n_out / 16 : 1;
+        long nseg = want < cap ? want : cap;
+        if (nseg < 1)
+            nseg = 1;
+        P.ts = (int)((n_out + nseg - 1) / nseg);
+        if (P.ts < 1)
+            P.ts = 1;
+    }
     if (a->variant != 1 && P.uf == 1.0f && P.hw >= 1 && P.hw <= 8 &&
         P.n_glob >= 2 * P.hw + 2 && P.n_glob < (1 << 22)) {
         // unit-spaced taps (octave 0): extended-line register-window kernels
@@ -1532,20 +1764,14 @@ int sift3d_hip_fir(const sift3d_hip_fir_args *a, void *stream)
             default: launch_fir_sweep_u1<8>(P, G, T, E, V, st); break;
             }
         }
+    } else if (a->variant != 1 && dyadic && (shift == 1 || shift == 2) && P.hw <= 8 &&
+               (a->axis == 0 || V == 4) &&
+               (shift == 1 ? launch_fir_dy_hw<1>(P, G, T, V, st) : launch_fir_dy_hw<2>(P, G, T, V, st))) {
+        // octaves 1 and 2: compile-time tap spacing, register-resident source window
     } else if (a->variant != 1 && dyadic && P.hw < 1024) {
-        const DyadTaps *dt = dyad_table(a->taps, a->width, P.uf, st);
-        if (!dt)
-            return fail("dyad_table", hipGetLastError(), __FILE__, __LINE__);
-        if (a->axis == 0) {
-            dim3 grid((a->nx + 255) / 256, a->ny * (a->z_hi - a->z_lo));
-            hipLaunchKernelGGL(k_fir_x_dyad, grid, dim3(256), 0, st, P, dt);
-        } else {
-            dim3 grid((G.ncols + 255) / 256, G.out_hi - G.out_lo);
-            if (V == 4)
-                hipLaunchKernelGGL(k_fir_sweep_dyad<4>, grid, dim3(256), 0, st, P, G, dt);
-            else
-                hipLaunchKernelGGL(k_fir_sweep_dyad<1>, grid, dim3(256), 0, st, P, G, dt);
-        }
+        DyadTaps dt;
+        dyad_table(dt, a->taps, a->width, P.uf);
+        launch_fir_dyad_generic(P, G, dt, V, st);
     } else {
         const size_t total = plane * (size_t)(a->z_hi - a->z_lo);
         hipLaunchKernelGGL(k_fir_literal, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, T);
