@@ -234,8 +234,13 @@ def main():
         kb = kernel_microbench(torch, hip, n)
         dom = max(kb, key=lambda k: k["avg_ms"])
         tr = None
-        if traffic and dom["kernel"] in traffic:
-            tr = traffic[dom["kernel"]]
+        if traffic:
+            # profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950
+            # corrections applied by profiles/pmc_fir.py) is keyed by the kernel symbol
+            hw = dom["kernel"].split("<")[1].rstrip(">")
+            sym = ("k_fir_x_u1<%s>" % hw) if dom["axis"] == 0 else ("k_fir_sweep_u1<%s, 4>" % hw)
+            if sym in traffic:
+                tr = traffic[sym]["hbm_bytes"]
         out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"],
                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": tr,

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Launch every octave-0 FIR kernel instance a few times at 512^3 (for rocprofv3 --pmc passes).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 profiles/pmc_fir.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 profiles/pmc_fir.py
+    python3 profiles/pmc_fir.py --parse gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/traffic.json
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SIG = [0.5387011637869722, 0.9732939207323564, 1.2262734984654078, 1.5450077936447955,
+       1.9465878414647133, 2.4525469969308156]
+
+
+def run(n=512, reps=3):
+    import torch
+    from sift3d_amd import api, hip
+    src = torch.empty((n, n, n), device="cuda")
+    dst = torch.empty_like(src)
+    hip.synth_lattice(src, 0, 11)
+    for s in SIG:
+        taps = api.gauss_filter(s)
+        for ax in range(3):
+            for _ in range(reps):
+                hip.fir(src, dst, ax, taps)
+    torch.cuda.synchronize()
+
+
+def parse(fetch_dir, write_dir, n=512):
+    """Per kernel: mean counter value per dispatch.  FETCH_SIZE / WRITE_SIZE are in KiB-ish units of
+    1024 B (guide: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024); on gfx950 FETCH_SIZE reports half
+    of the bytes of a wide coalesced streaming read, so it is doubled (MI355X_MICROARCH.md, HBM)."""
+    def load(d, name):
+        out = {}
+        for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != name:
+                    continue
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                gx = int(r["Grid_Size_X"]) if "Grid_Size_X" in r else 0
+                out.setdefault((k, gx), []).append(float(r["Counter_Value"]))
+        return out
+    fe, wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    res = {}
+    for (k, gx), v in fe.items():
+        if "fir" not in k:
+            continue
+        w = wr.get((k, gx), [0.0])
+        fetch_b = 2.0 * 1024.0 * sum(v) / len(v)
+        write_b = 1024.0 * sum(w) / len(w)
+        res[k] = dict(fetch_bytes=round(fetch_b), write_bytes=round(write_b),
+                                             hbm_bytes=round(fetch_b + write_b),
+                                             algorithmic_bytes=8 * n ** 3,
+                                             ratio=round((fetch_b + write_b) / (8.0 * n ** 3), 3),
+                                             dispatches=len(v))
+    return res
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--parse":
+        print(json.dumps(parse(sys.argv[2], sys.argv[3]), indent=1, sort_keys=True))
+    else:
+        run()

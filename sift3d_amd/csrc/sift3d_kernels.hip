@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     __shared__ __attribute__((aligned(16))) float sface[20 * 16];
     __shared__ float mw[8][65];   // mag * trilinear weight of the eight cells
     __shared__ float bw[3][65];   // barycentric weights
-    __shared__ int meta[64];      // ix | iy<<2 | iz<<4 | bin0<<6 | bin1<<10 | bin2<<14
+    __shared__ int meta[64];      // cell base bin | corner validity<<10 | bin0<<18 | bin1<<22 | bin2<<26
     __shared__ int svf[12];       // the five faces around each vertex, 5 bits each
     __shared__ int queue[DQ];     // xx | yy<<10 | zz<<20, window-relative, in scan order
     const uint32_t ki = blockIdx.x;
@@ -1235,6 +1235,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     const int half = lane >> 5, l5 = lane & 31;
     const int pc = l5 / 3, pj = l5 - 3 * pc;
     const int pdx = (pc >> 2) & 1, pdy = (pc >> 1) & 1, pdz = pc & 1;
+    const int coff = (pdx + 4 * pdy + 16 * pdz) * 12;  // bin offset of this lane's cell corner
     const bool committer = l5 < 24;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     __syncthreads();
@@ -1335,10 +1336,18 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                         mw[c][lane] = mag * wt;
                     }
                     bw[0][lane] = b0; bw[1][lane] = b1; bw[2][lane] = b2;
-                    // bins are addressed through the UNSWAPPED idx[] of the face (quirk Q1)
-                    meta[lane] = (int)vbx | ((int)vby << 2) | ((int)vbz << 4) |
-                                 (c_face_idx[face * 3] << 6) | (c_face_idx[face * 3 + 1] << 10) |
-                                 (c_face_idx[face * 3 + 2] << 14);
+                    // commit record: base bin of cell (ix,iy,iz), validity of the 8 trilinear
+                    // corners (sift.c:1349-1352), and the three vertex bins -- addressed through
+                    // the UNSWAPPED idx[] of the face (quirk Q1)
+                    const int ix = (int)vbx, iy = (int)vby, iz = (int)vbz;
+                    int valid = 0;
+#pragma unroll
+                    for (int c = 0; c < 8; c++)
+                        valid |= ((ix + ((c >> 2) & 1) < 4) && (iy + ((c >> 1) & 1) < 4) &&
+                                  (iz + (c & 1) < 4)) ? (1 << c) : 0;
+                    meta[lane] = ((ix + 4 * iy + 16 * iz) * 12) | (valid << 10) |
+                                 (c_face_idx[face * 3] << 18) | (c_face_idx[face * 3 + 1] << 22) |
+                                 (c_face_idx[face * 3 + 2] << 26);
                 }
             }
         }
@@ -1361,10 +1370,8 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
             int addr = -1;
             if (committer && v >= 0) {
                 const int mt = meta[v];
-                const int cxx = (mt & 3) + pdx, cyy = ((mt >> 2) & 3) + pdy,
-                          czz = ((mt >> 4) & 3) + pdz;
-                if (cxx < 4 && cyy < 4 && czz < 4) {                          // sift.c:1349-1352
-                    addr = (cxx + 4 * cyy + 16 * czz) * 12 + ((mt >> (6 + 4 * pj)) & 15);
+                if ((mt >> (10 + pc)) & 1) {                                  // sift.c:1349-1352
+                    addr = (mt & 1023) + coff + ((mt >> (18 + 4 * pj)) & 15);
                     val = mw[pc][v] * bw[pj][v];                              // sift.c:1371-1373
                 }
             }
