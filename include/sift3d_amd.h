@@ -156,6 +156,15 @@ typedef struct {
 SIFT3D_AMD_API int
 sift3d_hip_fir(const sift3d_hip_fir_args *args, void *stream);
 
+/* The y and z passes of one blur fused into one launch when both have tap spacing 1 (octave 0):
+ * dst = FIR_z(FIR_y(src)), bit-identical to two sift3d_hip_fir calls, without the intermediate
+ * volume touching HBM.  Slab arguments as for axis 2 of sift3d_hip_fir.  Returns SIFT3D_SUCCESS,
+ * SIFT3D_FAILURE, or 1 when the configuration is not covered (width > 17, nx % 4 != 0, unaligned
+ * buffers, an axis shorter than width + 1): the caller then issues the two passes itself. */
+SIFT3D_AMD_API int
+sift3d_hip_fir_yz_u1(const float *d_src, float *d_dst, int nx, int ny, int nz, const float *taps,
+                     int width, int n_glob, int off, int z_lo, int z_hi, void *stream);
+
 /* im_subtract (imutil.c:719-739) fused with the dogmax scan of detect_extrema
  * (sift.c:821-826): dst = a - b and *d_absmax = max(*d_absmax, max|dst|).
  * d_absmax may be NULL. */

@@ -953,6 +953,39 @@ static int blur_level(sift3d_detector *d, const float *src, float *dst, const in
     outs[0] = d->d_tmp_a;
     outs[1] = d->d_tmp_b;
     outs[2] = dst;
+    /* tap spacing 1 on y and z (octave 0 of a unit-spaced volume): x pass, then the fused
+     * y+z kernel -- the y-pass result never goes to HBM */
+    if ((float)(1.0 / lu[1]) == 1.0f && (float)(1.0 / lu[2]) == 1.0f && !getenv("SIFT3D_AMD_NO_FUSE")) {
+        sift3d_hip_fir_args a;
+        int rc;
+        memset(&a, 0, sizeof(a));
+        a.src = src; a.dst = d->d_tmp_a;
+        a.nx = dims[0]; a.ny = dims[1]; a.nz = dims[2];
+        a.axis = 0; a.width = f->width; a.taps = f->taps;
+        a.unit_factor = (float)(1.0 / lu[0]);
+        a.n_glob = dims[2]; a.z_lo = 0; a.z_hi = dims[2];
+        if (sift3d_hip_fir(&a, d->stream))
+            return SIFT3D_FAILURE;
+        rc = sift3d_hip_fir_yz_u1(d->d_tmp_a, dst, dims[0], dims[1], dims[2], f->taps, f->width,
+                                  dims[2], 0, 0, dims[2], d->stream);
+        if (rc == SIFT3D_SUCCESS)
+            return SIFT3D_SUCCESS;
+        if (rc != 1)
+            return SIFT3D_FAILURE;
+        in = d->d_tmp_a;                 /* not covered: finish with separate y and z passes */
+        for (ax = 1; ax < 3; ax++) {
+            memset(&a, 0, sizeof(a));
+            a.src = in; a.dst = outs[ax];
+            a.nx = dims[0]; a.ny = dims[1]; a.nz = dims[2];
+            a.axis = ax; a.width = f->width; a.taps = f->taps;
+            a.unit_factor = (float)(1.0 / lu[ax]);
+            a.n_glob = dims[2]; a.z_lo = 0; a.z_hi = dims[2];
+            if (sift3d_hip_fir(&a, d->stream))
+                return SIFT3D_FAILURE;
+            in = outs[ax];
+        }
+        return SIFT3D_SUCCESS;
+    }
     for (ax = 0; ax < 3; ax++) {
         sift3d_hip_fir_args a;
         memset(&a, 0, sizeof(a));

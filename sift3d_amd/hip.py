@@ -71,6 +71,8 @@ def lib():
         "sift3d_hip_absmax": (C.c_int, [vp, C.c_size_t, vp, vp]),
         "sift3d_hip_scale": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
         "sift3d_hip_fir": (C.c_int, [C.POINTER(FirArgs), vp]),
+        "sift3d_hip_fir_yz_u1": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
         "sift3d_hip_subtract_absmax": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp]),
         "sift3d_hip_downsample2": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
         "sift3d_hip_extrema_work_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -112,6 +114,22 @@ def fir(src, dst, axis, taps, unit_factor=1.0, n_glob=None, off=0, z_lo=0, z_hi=
                 nz if n_glob is None else n_glob, off, z_lo, nz if z_hi is None else z_hi, variant)
     _check(lib().sift3d_hip_fir(C.byref(a), current_stream()), "sift3d_hip_fir")
     return dst
+
+
+def fir_yz(src, dst, taps, n_glob=None, off=0, z_lo=0, z_hi=None):
+    """Fused y+z passes with tap spacing 1.  Returns False when the configuration is not covered
+    (the caller then issues the two passes separately)."""
+    nz, ny, nx = src.shape
+    assert src.is_contiguous() and dst.is_contiguous() and src.shape == dst.shape
+    taps = np.ascontiguousarray(taps, np.float32)
+    rc = lib().sift3d_hip_fir_yz_u1(src.data_ptr(), dst.data_ptr(), nx, ny, nz,
+                                    taps.ctypes.data_as(C.POINTER(C.c_float)), len(taps),
+                                    nz if n_glob is None else n_glob, off, z_lo,
+                                    nz if z_hi is None else z_hi, current_stream())
+    if rc == 1:
+        return False
+    _check(rc, "sift3d_hip_fir_yz_u1")
+    return True
 
 
 def absmax(src, out):

@@ -123,6 +123,9 @@ class HipBackend:
         self.hip.fir(src, dst, axis, taps, unit_factor=uf, n_glob=n_glob, off=off, z_lo=z_lo,
                      z_hi=z_hi)
 
+    def fir_yz(self, src, dst, taps, n_glob, off, z_lo, z_hi):
+        return self.hip.fir_yz(src, dst, taps, n_glob=n_glob, off=off, z_lo=z_lo, z_hi=z_hi)
+
     def subtract_absmax(self, a, b, dst, out):
         self.hip.subtract_absmax(a, b, dst, out)
 
@@ -341,11 +344,18 @@ class ShardedSift3D:
         a, b = dst.own()
         nx, ny, nz = self.g.dims[o]
         ufs = [np.float32(1.0 / lu[k]) for k in range(3)]   # unit = 1.0, sift.c:675
+        hw = len(f) // 2
+        reach = int(math.ceil(hw * float(ufs[2]))) + 1
         be.fir(src.t, ta.t, 0, f, ufs[0], nx, 0, a, b)
+        if ufs[1] == 1.0 and ufs[2] == 1.0 and hasattr(be, "fir_yz"):
+            # fused y+z kernel: it re-derives the y pass on the halo planes itself, so the
+            # exchanged halo is the x-pass output
+            self._halo(ta, reach)
+            if be.fir_yz(ta.t, dst.t, f, nz, dst.off, a, b):
+                return
         be.fir(ta.t, tb.t, 1, f, ufs[1], ny, 0, a, b)
         if self.g.sharded(o):
-            hw = len(f) // 2
-            self._halo(tb, int(math.ceil(hw * float(ufs[2]))) + 1)
+            self._halo(tb, reach)
         be.fir(tb.t, dst.t, 2, f, ufs[2], nz, dst.off, a, b)
 
     def _pyramid(self):

@@ -162,6 +162,40 @@ def test_fir_slab_z(gpu, oracle_mod):
             np.testing.assert_array_equal(got[z0 - lo:z1 - lo], whole[z0:z1])
 
 
+@pytest.mark.parametrize("shape", [(40, 48, 64), (70, 33, 128), (24, 100, 20)])
+def test_fir_fused_yz_vs_oracle(gpu, oracle_mod, shape):
+    """Fused y+z kernel == FIR_z(FIR_y(.)) of the oracle, whole volume and as Z-slabs (partial
+    tiles in x and y, both global z faces, interior slab faces)."""
+    api, hip, torch = gpu
+    rng = np.random.default_rng(shape[0])
+    vol = rng.standard_normal(shape).astype(np.float32)
+    nz = shape[0]
+    for sigma in (0.5387011637869722, 1.2262734984654078, 2.4525469969308156):
+        taps = oracle_mod.gauss_taps(sigma)
+        ty, r = oracle_mod.fir_axis(vol, taps, 1, uf=np.float32(1.0), mode=0)
+        want, r2 = oracle_mod.fir_axis(ty, taps, 2, uf=np.float32(1.0), mode=0)
+        assert r == 0 and r2 == 0
+        guard = 4096
+        big = torch.full((vol.size + 2 * guard,), float("nan"), device="cuda")
+        src = big[guard:guard + vol.size].view(vol.shape)
+        src.copy_(torch.from_numpy(vol))
+        dst = torch.full(vol.shape, float("nan"), device="cuda")
+        assert hip.fir_yz(src, dst, taps)
+        np.testing.assert_array_equal(dst.cpu().numpy(), want)
+        reach = len(taps) // 2 + 1
+        for z0, z1 in ((0, nz // 3), (nz // 3, 2 * nz // 3), (2 * nz // 3, nz)):
+            lo, hi = max(0, z0 - reach), min(nz, z1 + reach)
+            big = torch.full(((hi - lo) * shape[1] * shape[2] + 2 * guard,), float("nan"), device="cuda")
+            s2 = big[guard:guard + (hi - lo) * shape[1] * shape[2]].view((hi - lo,) + shape[1:])
+            s2.copy_(torch.from_numpy(vol[lo:hi]))
+            d2 = torch.full(s2.shape, float("nan"), device="cuda")
+            assert hip.fir_yz(s2, d2, taps, n_glob=nz, off=lo, z_lo=z0 - lo, z_hi=z1 - lo)
+            np.testing.assert_array_equal(d2.cpu().numpy()[z0 - lo:z1 - lo], want[z0:z1])
+    # not covered: nx % 4 != 0 -> the caller must fall back
+    odd = torch.zeros((20, 20, 22), device="cuda")
+    assert hip.fir_yz(odd, torch.empty_like(odd), oracle_mod.gauss_taps(1.0)) is False
+
+
 def test_scale_dog_downsample(gpu, oracle_mod):
     api, hip, torch = gpu
     rng = np.random.default_rng(3)
