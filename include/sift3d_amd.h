@@ -103,6 +103,9 @@ SIFT3D_AMD_API void sift3d_hip_host_free(void *h_ptr);
 SIFT3D_AMD_API int sift3d_hip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 SIFT3D_AMD_API int sift3d_hip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 SIFT3D_AMD_API int sift3d_hip_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
+SIFT3D_AMD_API int sift3d_hip_memcpy2d_d2h(void *h_dst, size_t dst_pitch, const void *d_src,
+                                           size_t src_pitch, size_t width, size_t height, void *stream);
+SIFT3D_AMD_API int sift3d_hip_stream_wait_event(void *stream, void *ev);
 SIFT3D_AMD_API int sift3d_hip_memset(void *d_dst, int byte, size_t bytes, void *stream);
 SIFT3D_AMD_API void *sift3d_hip_stream_create(void);
 SIFT3D_AMD_API void sift3d_hip_stream_destroy(void *stream);

@@ -76,14 +76,13 @@ struct _sift3d_keypoint_store {
     int nx, ny, nz;
 };
 
-typedef struct {
-    float hist[DESC_NUMEL];
-    double xd, yd, zd, sd;
-} descriptor_t;
-
+/* Descriptors are kept as two arrays: the histograms (num x 768 floats, page-locked so that
+ * they are the direct target of the device-to-host copy) and the coordinates. */
 struct _sift3d_descriptor_store {
-    descriptor_t *buf;
-    size_t num;
+    float *hist;       /* [num][768]: cell = cx + 4 cy + 16 cz, 12 vertex bins each */
+    double *xyzsd;     /* [num][4]: xd, yd, zd (octave-0 voxels), sd */
+    size_t num, cap;
+    int pinned;
     int nx, ny, nz;
 };
 
@@ -108,8 +107,9 @@ struct _sift3d_detector {
     filter_t *filt;        /* [0] first blur, [1..ngl-1] octave filters */
     int nfilt;
     /* device state */
-    void *stream;
+    void *stream, *copy_stream;
     void *ev[8];
+    void *ev_chunk[8];
     float *d_im, *d_tmp_a, *d_tmp_b, *d_in;
     size_t in_cap;
     float **d_g, **d_d;    /* [num_octaves*ngl], [num_octaves*ndl] */
@@ -122,7 +122,7 @@ struct _sift3d_detector {
     void *d_work;
     size_t work_bytes;
     sift3d_hip_kp *d_kp, *h_kp;
-    float *d_hist, *h_hist;
+    float *d_hist;
     uint32_t kp_cap;
     int have_pyramid;
     int ncand;
@@ -370,11 +370,24 @@ sift3d_descriptor_store *sift3d_make_descriptor_store()
     return (sift3d_descriptor_store *)calloc(1, sizeof(sift3d_descriptor_store));
 }
 
+static void desc_store_release(sift3d_descriptor_store *d)
+{
+    if (d->pinned)
+        sift3d_hip_host_free(d->hist);
+    else
+        free(d->hist);
+    free(d->xyzsd);
+    d->hist = NULL;
+    d->xyzsd = NULL;
+    d->num = d->cap = 0;
+    d->pinned = 0;
+}
+
 void sift3d_free_descriptor_store(sift3d_descriptor_store *d)
 {
     if (!d)
         return;
-    free(d->buf);
+    desc_store_release(d);
     free(d);
 }
 
@@ -422,12 +435,12 @@ int sift3d_descriptor_store_to_mat_rm(const sift3d_descriptor_store *const store
     if (mat_resize(mat, rows, cols, SIFT3D_FLOAT))
         return SIFT3D_FAILURE;
     for (i = 0; i < rows; i++) {
-        const descriptor_t *d = store->buf + i;
         float *row = (float *)mat->data + (size_t)cols * i;
-        row[0] = (float)d->xd;
-        row[1] = (float)d->yd;
-        row[2] = (float)d->zd;
-        memcpy(row + 3, d->hist, sizeof(float) * DESC_NUMEL); /* col = 3 + 12*cell + bin */
+        row[0] = (float)store->xyzsd[4 * (size_t)i];
+        row[1] = (float)store->xyzsd[4 * (size_t)i + 1];
+        row[2] = (float)store->xyzsd[4 * (size_t)i + 2];
+        memcpy(row + 3, store->hist + (size_t)DESC_NUMEL * i,
+               sizeof(float) * DESC_NUMEL);            /* col = 3 + 12*cell + bin */
     }
     return SIFT3D_SUCCESS;
 }
@@ -878,9 +891,11 @@ void sift3d_free_detector(sift3d_detector *d)
     sift3d_hip_host_free(d->h_R);
     sift3d_hip_host_free(d->h_keep);
     sift3d_hip_host_free(d->h_kp);
-    sift3d_hip_host_free(d->h_hist);
-    for (i = 0; i < 8; i++)
+    for (i = 0; i < 8; i++) {
         sift3d_hip_event_destroy(d->ev[i]);
+        sift3d_hip_event_destroy(d->ev_chunk[i]);
+    }
+    sift3d_hip_stream_destroy(d->copy_stream);
     sift3d_hip_stream_destroy(d->stream);
     free(d);
 }
@@ -900,10 +915,10 @@ static int ensure_device(sift3d_detector *d)
         ERR("sift3d_amd: no HIP device is available; this library has no CPU path \n");
         return SIFT3D_FAILURE;
     }
-    if (!(d->stream = sift3d_hip_stream_create()))
+    if (!(d->stream = sift3d_hip_stream_create()) || !(d->copy_stream = sift3d_hip_stream_create()))
         return SIFT3D_FAILURE;
     for (i = 0; i < 8; i++)
-        if (!(d->ev[i] = sift3d_hip_event_create()))
+        if (!(d->ev[i] = sift3d_hip_event_create()) || !(d->ev_chunk[i] = sift3d_hip_event_create()))
             return SIFT3D_FAILURE;
     return upload_mesh();
 }
@@ -1266,13 +1281,11 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
         sift3d_hip_free(d->d_kp);
         sift3d_hip_free(d->d_hist);
         sift3d_hip_host_free(d->h_kp);
-        sift3d_hip_host_free(d->h_hist);
         d->kp_cap = 0;
         d->d_kp = (sift3d_hip_kp *)sift3d_hip_malloc(sizeof(sift3d_hip_kp) * (size_t)cap);
         d->d_hist = (float *)sift3d_hip_malloc(sizeof(float) * DESC_NUMEL * (size_t)cap);
         d->h_kp = (sift3d_hip_kp *)sift3d_hip_host_alloc(sizeof(sift3d_hip_kp) * (size_t)cap);
-        d->h_hist = (float *)sift3d_hip_host_alloc(sizeof(float) * DESC_NUMEL * (size_t)cap);
-        if (!d->d_kp || !d->d_hist || !d->h_kp || !d->h_hist)
+        if (!d->d_kp || !d->d_hist || !d->h_kp)
             return SIFT3D_FAILURE;
         d->kp_cap = cap;
     }
@@ -1290,36 +1303,52 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
     desc->nx = d->odims[0][0];
     desc->ny = d->odims[0][1];
     desc->nz = d->odims[0][2];
-    {
-        descriptor_t *p = (descriptor_t *)realloc(desc->buf, sizeof(descriptor_t) * (size_t)num);
-        if (!p) {
-            free(desc->buf);
-            desc->buf = NULL;
-            desc->num = 0;
+    /* the store's histogram array is page-locked so that histograms land in it straight from
+     * HBM, chunk by chunk on a second stream while the next chunk's kernel runs */
+    if (!desc->pinned || (size_t)num > desc->cap) {
+        const size_t cap = (size_t)num + (size_t)num / 8 + 64;
+        desc_store_release(desc);
+        desc->hist = (float *)sift3d_hip_host_alloc(sizeof(float) * DESC_NUMEL * cap);
+        desc->xyzsd = (double *)malloc(sizeof(double) * 4 * cap);
+        if (!desc->hist || !desc->xyzsd) {
+            desc->pinned = desc->hist != NULL;
+            desc_store_release(desc);
             return SIFT3D_FAILURE;
         }
-        desc->buf = p;
-        desc->num = (size_t)num;
+        desc->pinned = 1;
+        desc->cap = cap;
     }
+    desc->num = (size_t)num;
     sift3d_hip_event_record(d->ev[6], d->stream);
-    if (sift3d_hip_memcpy_h2d(d->d_kp, d->h_kp, sizeof(sift3d_hip_kp) * (size_t)num, d->stream) ||
-        sift3d_hip_describe(d->d_levels, d->d_kp, (uint32_t)num, d->d_hist, d->stream) ||
-        sift3d_hip_memcpy_d2h(d->h_hist, d->d_hist, sizeof(float) * DESC_NUMEL * (size_t)num,
-                              d->stream))
+    if (sift3d_hip_memcpy_h2d(d->d_kp, d->h_kp, sizeof(sift3d_hip_kp) * (size_t)num, d->stream))
         return SIFT3D_FAILURE;
+    {
+        const int nch = 1; /* chunked kernel/copy overlap measured slower (tail effects): one launch */
+        int c;
+        for (c = 0; c < nch; c++) {
+            const size_t i0 = (size_t)num * c / nch, i1 = (size_t)num * (c + 1) / nch;
+            if (i1 == i0)
+                continue;
+            if (sift3d_hip_describe(d->d_levels, d->d_kp + i0, (uint32_t)(i1 - i0),
+                                    d->d_hist + DESC_NUMEL * i0, d->stream) ||
+                sift3d_hip_event_record(d->ev_chunk[c], d->stream) ||
+                sift3d_hip_stream_wait_event(d->copy_stream, d->ev_chunk[c]) ||
+                sift3d_hip_memcpy_d2h(desc->hist + DESC_NUMEL * i0, d->d_hist + DESC_NUMEL * i0,
+                                      sizeof(float) * DESC_NUMEL * (i1 - i0), d->copy_stream))
+                return SIFT3D_FAILURE;
+        }
+    }
     sift3d_hip_event_record(d->ev[7], d->stream);
-    if (sift3d_hip_stream_sync(d->stream))
-        return SIFT3D_FAILURE;
     for (i = 0; i < num; i++) {
         const keypoint_t *k = kp->buf + i;
-        descriptor_t *q = desc->buf + i;
         const double f = ldexp(1.0, k->o);             /* sift.c:1459, 1530-1533 */
-        memcpy(q->hist, d->h_hist + (size_t)DESC_NUMEL * i, sizeof(q->hist));
-        q->xd = k->xd * f;
-        q->yd = k->yd * f;
-        q->zd = k->zd * f;
-        q->sd = k->sd;
+        desc->xyzsd[4 * (size_t)i] = k->xd * f;
+        desc->xyzsd[4 * (size_t)i + 1] = k->yd * f;
+        desc->xyzsd[4 * (size_t)i + 2] = k->zd * f;
+        desc->xyzsd[4 * (size_t)i + 3] = k->sd;
     }
+    if (sift3d_hip_stream_sync(d->stream) || sift3d_hip_stream_sync(d->copy_stream))
+        return SIFT3D_FAILURE;
     d->t[5] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[6], d->ev[7]);
     d->t[8] = now_s() - t_start;
     return SIFT3D_SUCCESS;

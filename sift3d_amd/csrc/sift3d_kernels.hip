@@ -119,6 +119,20 @@ int sift3d_hip_memcpy_d2d(void *d, const void *s, size_t bytes, void *stream)
     return SIFT3D_SUCCESS;
 }
 
+int sift3d_hip_memcpy2d_d2h(void *h, size_t dpitch, const void *d, size_t spitch, size_t width,
+                            size_t height, void *stream)
+{
+    HIPCHK(hipMemcpy2DAsync(h, dpitch, d, spitch, width, height, hipMemcpyDeviceToHost,
+                            (hipStream_t)stream));
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_stream_wait_event(void *stream, void *ev)
+{
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
+    return SIFT3D_SUCCESS;
+}
+
 int sift3d_hip_memset(void *d, int byte, size_t bytes, void *stream)
 {
     HIPCHK(hipMemsetAsync(d, byte, bytes, (hipStream_t)stream));
@@ -1225,50 +1239,81 @@ __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restric
 
     double dacc = 0.0; // lanes 0..5: A00 A01 A02 A11 A12 A22
     float facc = 0.0f; // lanes 6..8: vd_win x y z
+    __shared__ int queue[256];   // in-sphere voxels, window relative, in scan order
+    uint32_t qhead = 0, qtail = 0;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    // 64 queued (in-sphere) voxels: their nine terms in parallel, then added in voxel order by
+    // the nine accumulator lanes.  Lanes beyond `cnt` contribute exact zeros (a no-op).
+    auto batch = [&](int cnt) {
+        const bool in = lane < cnt;
+        float gx = 0.f, gy = 0.f, gz = 0.f, w = 0.f;
+        if (in) {
+            const int pk = queue[(qhead + lane) & 255];
+            const int x = B.xs + (pk & 1023), y = B.ys + ((pk >> 10) & 1023), z = B.zs + (pk >> 20);
+            const float dx = ((float)x - cx) * L.ux;              // sift.c:102-104
+            const float dy = ((float)y - cy) * L.uy;
+            const float dz = ((float)z - cz) * L.uz;
+            const float sq = dx * dx + dy * dy + dz * dz;         // sift.c:105
+            w = s3d_expf((float)(-0.5 * (double)sq / sig2));      // sift.c:972
+            grad_iso(L, x, y, z - L.z_off, gx, gy, gz);
+        }
+        // sift.c:978-987
+        td[0][lane] = in ? (double)gx * (double)gx * (double)w : 0.0;
+        td[1][lane] = in ? (double)gx * (double)gy * (double)w : 0.0;
+        td[2][lane] = in ? (double)gx * (double)gz * (double)w : 0.0;
+        td[3][lane] = in ? (double)gy * (double)gy * (double)w : 0.0;
+        td[4][lane] = in ? (double)gy * (double)gz * (double)w : 0.0;
+        td[5][lane] = in ? (double)gz * (double)gz * (double)w : 0.0;
+        tf[0][lane] = in ? gx * w : 0.0f;
+        tf[1][lane] = in ? gy * w : 0.0f;
+        tf[2][lane] = in ? gz * w : 0.0f;
+        __syncthreads();
+        if (lane < 6) {
+#pragma unroll
+            for (int j = 0; j < 64; j++)
+                dacc += td[lane][j];
+        } else if (lane < 9) {
+#pragma unroll
+            for (int j = 0; j < 64; j++)
+                facc += tf[lane - 6][j];
+        }
+        __syncthreads();
+    };
 
     for (int z = B.zs; z <= B.ze; z++) {
         const float dz = ((float)z - cz) * L.uz;
+        int yy = bx > 0 ? lane / bx : 0, xx = bx > 0 ? lane - yy * bx : 0;
         for (int c0 = 0; c0 < npl; c0 += 64) {
-            const int i = c0 + lane;
             bool in = false;
-            float gx = 0.f, gy = 0.f, gz = 0.f, w = 0.f;
-            if (i < npl) {
-                const int yy = i / bx, xx = i - yy * bx;
-                const int x = B.xs + xx, y = B.ys + yy;
-                const float dx = ((float)x - cx) * L.ux;          // sift.c:102-104
-                const float dy = ((float)y - cy) * L.uy;
-                const float sq = dx * dx + dy * dy + dz * dz;     // sift.c:105
-                if (!((double)sq > rad2)) {                       // sift.c:106 (double)
-                    in = true;
-                    w = s3d_expf((float)(-0.5 * (double)sq / sig2)); // sift.c:972
-                    grad_iso(L, x, y, z - L.z_off, gx, gy, gz);
-                }
+            int pk = 0;
+            if (c0 + lane < npl) {
+                const float dx = ((float)(B.xs + xx) - cx) * L.ux;
+                const float dy = ((float)(B.ys + yy) - cy) * L.uy;
+                const float sq = dx * dx + dy * dy + dz * dz;
+                in = !((double)sq > rad2);                        // sift.c:106 (double)
+                pk = xx | (yy << 10) | ((z - B.zs) << 20);
             }
-            if (__ballot(in) == 0ull)
-                continue; // nothing to add in this chunk (adding exact zeros is a no-op)
-            // sift.c:978-987
-            td[0][lane] = in ? (double)gx * (double)gx * (double)w : 0.0;
-            td[1][lane] = in ? (double)gx * (double)gy * (double)w : 0.0;
-            td[2][lane] = in ? (double)gx * (double)gz * (double)w : 0.0;
-            td[3][lane] = in ? (double)gy * (double)gy * (double)w : 0.0;
-            td[4][lane] = in ? (double)gy * (double)gz * (double)w : 0.0;
-            td[5][lane] = in ? (double)gz * (double)gz * (double)w : 0.0;
-            tf[0][lane] = in ? gx * w : 0.0f;
-            tf[1][lane] = in ? gy * w : 0.0f;
-            tf[2][lane] = in ? gz * w : 0.0f;
-            __syncthreads();
-            if (lane < 6) {
-#pragma unroll 8
-                for (int j = 0; j < 64; j++)
-                    dacc += td[lane][j];
-            } else if (lane < 9) {
-#pragma unroll 8
-                for (int j = 0; j < 64; j++)
-                    facc += tf[lane - 6][j];
+            xx += 64;
+            while (xx >= bx) {
+                xx -= bx;
+                yy++;
             }
+            const unsigned long long m = __ballot(in);
+            if (m == 0ull)
+                continue;
+            if (in)
+                queue[(qtail + (uint32_t)__popcll(m & lt_mask)) & 255] = pk;
+            qtail += (uint32_t)__popcll(m);
             __syncthreads();
+            if (qtail - qhead >= 64) {
+                batch(64);
+                qhead += 64;
+            }
         }
     }
+    if (qtail != qhead)
+        batch((int)(qtail - qhead));
     // gather the nine sums on every lane (uniform epilogue, no divergence)
     double A[9];
     A[0] = __shfl(dacc, 0, 64); A[1] = __shfl(dacc, 1, 64); A[2] = __shfl(dacc, 2, 64);
@@ -1337,7 +1382,7 @@ __constant__ int c_face_idx[60];   // unswapped vertex ids of each face (bins, q
 __constant__ float c_verts[12 * 3];// unit vertices
 __constant__ int c_vert_faces[12 * 5]; // the five faces around each vertex, ascending
 
-constexpr int DQ = 128; // compaction queue length (power of two, >= 2 * 64)
+constexpr int DQ = 256; // compaction queue length (power of two, >= 3 * 64)
 
 __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restrict__ levels,
                                                  const sift3d_hip_kp *__restrict__ kps, uint32_t n,
@@ -1391,6 +1436,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     __syncthreads();
 
     uint32_t qhead = 0, qtail = 0; // wave-uniform
+    bool pend = false;             // registers pv/ppk hold the batch starting at qhead
 
     // Window voxel -> (window test, spatial bins).  Same float expressions in the scan and
     // in the batch, so both see identical values.
@@ -1413,16 +1459,33 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     };
 
     // One batch: the next `cnt` (<= 64) queued voxels, in scan order.
-    auto batch = [&](int cnt) {
+    // The six gradient samples of a batch are fetched one batch ahead (registers pv/ppk), so
+    // their HBM/L2 latency overlaps the previous batch's binning and commit.
+    float pv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    int ppk = 0;
+    auto prefetch = [&](uint32_t start, int cnt) {
+        if (lane < cnt) {
+            ppk = queue[(start + lane) & (DQ - 1)];
+            const int x = B.xs + (ppk & 1023), y = B.ys + ((ppk >> 10) & 1023),
+                      zl = B.zs + (ppk >> 20) - L.z_off;
+            const size_t ys = L.nx, zs = (size_t)L.nx * L.ny;
+            const float *p = L.data + (size_t)x + ys * y + zs * zl;
+            pv[0] = p[1]; pv[1] = *(p - 1); pv[2] = p[ys]; pv[3] = *(p - ys);
+            pv[4] = p[zs]; pv[5] = *(p - zs);
+        }
+    };
+    auto batch = [&](int cnt, const float *cv, int pk) {
         bool ok = false;
         if (ablate & 2) return;
         if (lane < cnt) {
-            const int pk = queue[(qhead + lane) & (DQ - 1)];
             const int x = B.xs + (pk & 1023), y = B.ys + ((pk >> 10) & 1023), z = B.zs + (pk >> 20);
             float sq, vbx, vby, vbz;
             window(x, y, z, sq, vbx, vby, vbz);
-            float gx, gy, gz;
-            grad_iso(L, x, y, z - L.z_off, gx, gy, gz);
+            // IM_GET_GRAD_ISO (sift.c:140-145, immacros.h:105-111)
+            float gx = 0.5f * (cv[0] - cv[1]), gy = 0.5f * (cv[2] - cv[3]), gz = 0.5f * (cv[4] - cv[5]);
+            gx *= 1.0f / L.ux;
+            gy *= 1.0f / L.uy;
+            gz *= 1.0f / L.uz;
             const float w = s3d_expf(-0.5f * sq / sig2);           // sift.c:1498
             gx = gx * w; gy = gy * w; gz = gz * w;
             const float rx = R[0] * gx + R[3] * gy + R[6] * gz;    // sift.c:1502
@@ -1501,52 +1564,53 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                 }
             }
         }
-        unsigned long long m = __ballot(ok);
-        if (ablate & 1) m = 0;
+        if (!ok)
+            meta[lane] = 0;            // no valid corner -> nothing is committed for this voxel
         __syncthreads();
-        // Ordered commit, two voxels per iteration.  24 lanes per voxel (8 cells x 3 face
-        // vertices) each own one distinct histogram bin, so a voxel's 24 adds are ONE plain LDS
-        // read-modify-write; the first voxel's RMW is issued before the second's and a wave's
-        // DS operations execute in issue order, so every bin receives its contributions in the
-        // reference's voxel order (sift.c:1340-1373) and the float sums are bit-identical.
-        // (LDS float atomics would also be ordered but retire < 1 lane-add/clk/CU.)
-        while (m) {
-            const int va = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int vb2 = m ? __ffsll((long long)m) - 1 : -1;
-            m &= m - 1;
-            const int v = half ? vb2 : va;
-            float val = 0.0f;
-            int addr = -1;
-            if (committer && v >= 0) {
+        // Ordered commit, two voxels per iteration (2i by lanes 0..23, 2i+1 by lanes 32..55).
+        // 24 lanes per voxel (8 cells x 3 face vertices) each own one distinct histogram bin,
+        // so a voxel's 24 adds are ONE plain LDS read-modify-write; the first voxel's RMW is
+        // issued before the second's and a wave's DS operations execute in issue order, so every
+        // bin receives its contributions in the reference's voxel order (sift.c:1340-1373) and
+        // the float sums are bit-identical.  (LDS float atomics would also be ordered but retire
+        // < 1 lane-add/clk/CU.)  Fully unrolled: all LDS addresses are base + immediate.
+        if (!(ablate & 1)) {
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const int v = 2 * i + half;
                 const int mt = meta[v];
-                if ((mt >> (10 + pc)) & 1) {                                  // sift.c:1349-1352
-                    addr = (mt & 1023) + coff + ((mt >> (18 + 4 * pj)) & 15);
-                    val = mw[pc][v] * bw[pj][v];                              // sift.c:1371-1373
-                }
+                const bool on = committer && ((mt >> (10 + pc)) & 1);         // sift.c:1349-1352
+                const int addr = (mt & 1023) + coff + ((mt >> (18 + 4 * pj)) & 15);
+                const float val = mw[pc][v] * bw[pj][v];                      // sift.c:1371-1373
+                if (half == 0 && on)
+                    hist[addr] = hist[addr] + val;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (half == 1 && on)
+                    hist[addr] = hist[addr] + val;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            if (half == 0 && addr >= 0)
-                hist[addr] = hist[addr] + val;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (half == 1 && addr >= 0)
-                hist[addr] = hist[addr] + val;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
     };
 
     for (int z = B.zs; z <= B.ze; z++) {
+        // (yy, xx) of this lane's voxel in the plane, advanced by 64 per chunk without a division
+        int yy = bx > 0 ? lane / bx : 0, xx = bx > 0 ? lane - yy * bx : 0;
         for (int c0 = 0; c0 < npl; c0 += 64) {
             const int i = c0 + lane;
             bool in = false;
             int pk = 0;
             if (i < npl) {
-                const int yy = i / bx, xx = i - yy * bx;
                 float sq, vbx, vby, vbz;
                 in = window(B.xs + xx, B.ys + yy, z, sq, vbx, vby, vbz);
                 pk = xx | (yy << 10) | ((z - B.zs) << 20);
+            }
+            xx += 64;
+            while (xx >= bx) {
+                xx -= bx;
+                yy++;
             }
             const unsigned long long m = __ballot(in);
             if (m == 0ull)
@@ -1555,14 +1619,34 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                 queue[(qtail + (uint32_t)__popcll(m & lt_mask)) & (DQ - 1)] = pk;
             qtail += (uint32_t)__popcll(m);
             __syncthreads();
-            if (qtail - qhead >= 64) {
-                batch(64);
+            if (!pend && qtail - qhead >= 64) {
+                prefetch(qhead, 64);
+                pend = true;
+            }
+            if (pend && qtail - qhead >= 128) {
+                float cv[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++)
+                    cv[k] = pv[k];
+                const int cpk = ppk;
+                prefetch(qhead + 64, 64);          // next batch's loads fly during this one
+                batch(64, cv, cpk);
                 qhead += 64;
             }
         }
     }
-    if (qtail != qhead)
-        batch((int)(qtail - qhead));
+    while (qtail != qhead) {
+        const int cnt = min(64u, qtail - qhead);
+        if (!pend)
+            prefetch(qhead, cnt);
+        pend = false;
+        float cv[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            cv[k] = pv[k];
+        batch(cnt, cv, ppk);
+        qhead += cnt;
+    }
     __syncthreads();
     // normalize_desc -> clamp -> normalize_desc (sift.c:1402-1429, 1514-1526).  The double
     // sum runs in element order on every lane (uniform), as in the reference.
