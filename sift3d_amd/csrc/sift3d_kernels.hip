@@ -981,16 +981,33 @@ __global__ __launch_bounds__(256) void k_sub_absmax(const float *__restrict__ a,
     const size_t nthr = (size_t)gridDim.x * blockDim.x;
     const size_t n4 = n >> 2;
     float m = 0.0f;
-    for (size_t i = tid; i < n4; i += nthr) {
+    // four independent 16-byte load pairs in flight per thread and iteration
+    size_t i = tid;
+    for (; i + 3 * nthr < n4; i += 4 * nthr) {
+        float4 u[4], v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u[k] = ld4(a + 4 * (i + k * nthr));
+            v[k] = ld4(b + 4 * (i + k * nthr));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float4 r;
+            r.x = u[k].x - v[k].x; r.y = u[k].y - v[k].y; r.z = u[k].z - v[k].z; r.w = u[k].w - v[k].w;
+            st4(dst + 4 * (i + k * nthr), r);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
+        }
+    }
+    for (; i < n4; i += nthr) {
         const float4 u = ld4(a + 4 * i), v = ld4(b + 4 * i);
         float4 r;
         r.x = u.x - v.x; r.y = u.y - v.y; r.z = u.z - v.z; r.w = u.w - v.w;
         st4(dst + 4 * i, r);
         m = fmaxf(m, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
     }
-    for (size_t i = 4 * n4 + tid; i < n; i += nthr) {
-        const float r = a[i] - b[i];
-        dst[i] = r;
+    for (size_t j = 4 * n4 + tid; j < n; j += nthr) {
+        const float r = a[j] - b[j];
+        dst[j] = r;
         m = fmaxf(m, fabsf(r));
     }
     if (out) {

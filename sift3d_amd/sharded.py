@@ -132,17 +132,66 @@ class HipBackend:
     def downsample2(self, src, dst):
         self.hip.downsample2(src, dst)
 
-    def extrema(self, levels, nx, ny, nz, peak):
-        return self.hip.extrema(levels, nx, ny, nz, peak)
-
     def level_table(self, levels):
         return self.hip.level_table(levels)[0]
 
-    def orient(self, table, cands, corner):
-        return self.hip.orient(table, cands, corner)
+    def extrema_orient(self, specs, table, peak, corner):
+        """detect_extrema for every octave (one shared candidate buffer, device-side running
+        count, a single host sync) followed by assign_orientations on the device-resident
+        candidates.  specs: [(levels, nx, ny, nz_local)].  Returns host arrays (cands, R, keep)."""
+        torch, hip = self.torch, self.hip
+        L = hip.lib()
+        wb = max(L.sift3d_hip_extrema_work_bytes(nx, ny, nz, len(lv)) for lv, nx, ny, nz in specs)
+        if getattr(self, "_work", None) is None or self._work.numel() < wb:
+            self._work = torch.empty(wb, dtype=torch.uint8, device="cuda")
+        if getattr(self, "_cap", 0) == 0:
+            self._cap = 1 << 18
+            self._count = torch.zeros(1, dtype=torch.int32, device="cuda")
+        while True:
+            if getattr(self, "_cand", None) is None or self._cand.numel() < self._cap * 12:
+                self._cand = torch.empty(self._cap * 12, dtype=torch.uint8, device="cuda")
+                self._R = torch.empty((self._cap, 9), dtype=torch.float32, device="cuda")
+                self._keep = torch.empty(self._cap, dtype=torch.int32, device="cuda")
+            self._count.zero_()
+            for lv, nx, ny, nz in specs:
+                arr = (hip.ExtremaLevel * len(lv))()
+                for i, l in enumerate(lv):
+                    arr[i] = hip.ExtremaLevel(l["prev"].data_ptr(), l["cur"].data_ptr(),
+                                              l["next"].data_ptr(), l["absmax"].data_ptr(),
+                                              l["z_lo"], l["z_hi"], l["tag"])
+                hip._check(L.sift3d_hip_extrema(arr, len(lv), nx, ny, nz, float(peak),
+                                                self._cand.data_ptr(), self._cap,
+                                                self._count.data_ptr(), self._work.data_ptr(),
+                                                self._work.numel(), hip.current_stream()),
+                           "sift3d_hip_extrema")
+            n = int(self._count.item())
+            if n <= self._cap:
+                break
+            self._cap = n + n // 4 + 1024
+        if n == 0:
+            return (np.zeros(0, hip.CAND_DTYPE), np.zeros((0, 9), np.float32), np.zeros(0, np.int32))
+        hip._check(L.sift3d_hip_orient(table.data_ptr(), self._cand.data_ptr(), n, float(corner),
+                                       self._R.data_ptr(), self._keep.data_ptr(),
+                                       hip.current_stream()), "sift3d_hip_orient")
+        cands = self._cand[:n * 12].cpu().numpy().view(hip.CAND_DTYPE)
+        return cands, self._R[:n].cpu().numpy(), self._keep[:n].cpu().numpy()
 
     def describe(self, table, kps):
-        return self.hip.describe(table, kps)
+        torch, hip = self.torch, self.hip
+        n = len(kps)
+        if n == 0:
+            return np.zeros((0, 768), np.float32)
+        if getattr(self, "_hist", None) is None or self._hist.shape[0] < n:
+            cap = n + n // 8 + 64
+            self._hist = torch.empty((cap, 768), dtype=torch.float32, device="cuda")
+            self._hist_host = torch.empty((cap, 768), dtype=torch.float32, pin_memory=True)
+        dk = torch.from_numpy(np.ascontiguousarray(kps).view(np.uint8)).cuda()
+        hip._check(hip.lib().sift3d_hip_describe(table.data_ptr(), dk.data_ptr(), n,
+                                                 self._hist.data_ptr(), hip.current_stream()),
+                   "sift3d_hip_describe")
+        self._hist_host[:n].copy_(self._hist[:n], non_blocking=True)
+        torch.cuda.synchronize()
+        return self._hist_host[:n].numpy()
 
     def synth(self, t, z_off, seed):
         self.hip.synth_lattice(t, z_off, seed)
@@ -196,6 +245,7 @@ class ShardedSift3D:
             self.filters.append(self.be.gauss_filter(math.sqrt(s_next * s_next - s_cur * s_cur)))
         self._alloc()
         self.t_pyr = 0.0
+        self._table = None
         self.ncand = 0
         self.kp = np.zeros(0, KP_DTYPE)
         self.my_kp_idx = np.zeros(0, np.int64)
@@ -414,6 +464,9 @@ class ShardedSift3D:
             nx, ny, nz = self.g.dims[o]
             ufs = [np.float32(1.0 / lu[k]) for k in range(3)]
             be.fir(src.t, ta.t, 0, f, ufs[0], nx, 0, 0, nz)
+            if (ufs[1] == 1.0 and ufs[2] == 1.0 and hasattr(be, "fir_yz") and
+                    be.fir_yz(ta.t, dst.t, f, nz, 0, 0, nz)):
+                return
             be.fir(ta.t, tb.t, 1, f, ufs[1], ny, 0, 0, nz)
             be.fir(tb.t, dst.t, 2, f, ufs[2], nz, 0, 0, nz)
 
@@ -440,8 +493,9 @@ class ShardedSift3D:
                 be.subtract_absmax(ga.t[lo:hi], gb.t[lo:hi], d.t[lo:hi], self.dogmax[o][s])
                 scal.append(self.dogmax[o][s])
         self._allreduce_max(scal)
-        # detect_extrema (sift.c:735-871) on the owned planes
-        recs = []
+        # detect_extrema (sift.c:735-871) on the owned planes of every octave, then
+        # assign_orientations (sift.c:1109-1167) for the local candidates
+        specs = []
         for o in range(g.num_octaves):
             nx, ny, nzo = g.dims[o]
             levels = []
@@ -452,45 +506,41 @@ class ShardedSift3D:
                 levels.append(dict(prev=self.D[o][s].t, cur=self.D[o][s + 1].t,
                                    next=self.D[o][s + 2].t, absmax=self.dogmax[o][s + 1],
                                    z_lo=zl, z_hi=max(zh, zl), tag=o * g.ngl + s + 1))
-            c = be.extrema(levels, nx, ny, self.D[o][0].t.shape[0], self.peak)
-            recs.append((o, off, c))
-        # assign_orientations (sift.c:1109-1167) for the local candidates
-        table_levels = []
-        for o in range(g.num_octaves):
-            for s in range(g.ngl):
-                lv = self.G[o][s]
-                table_levels.append(dict(data=lv.t, off=lv.off, nz_glob=lv.nz_glob,
-                                         units=self._lunits(o), octave=o, sd=self._scale(o, s - 1)))
-        self._table = be.level_table(table_levels)
-        local = np.concatenate([c for _, _, c in recs]) if recs else np.zeros(0)
-        R, keep = be.orient(self._table, local, self.corner)
-        # to global records
+            specs.append((levels, nx, ny, self.D[o][0].t.shape[0]))
+        if self._table is None:
+            table_levels = []
+            for o in range(g.num_octaves):
+                for s in range(g.ngl):
+                    lv = self.G[o][s]
+                    table_levels.append(dict(data=lv.t, off=lv.off, nz_glob=lv.nz_glob,
+                                             units=self._lunits(o), octave=o,
+                                             sd=self._scale(o, s - 1)))
+            self._table = be.level_table(table_levels)
+        local, R, keep = be.extrema_orient(specs, self._table, self.peak, self.corner)
+        # to global records (vectorised over all octaves)
+        oct_ = (local["tag"] // g.ngl).astype(np.int64)
+        dims = np.array(g.dims, np.int64)
+        offs = np.array([self.D[o][0].off for o in range(g.num_octaves)], np.int64)
+        idx = local["idx"].astype(np.int64)
+        nxv, nyv = dims[oct_, 0], dims[oct_, 1]
         out = np.zeros(len(local), GCAND_DTYPE)
-        pos = 0
-        for o, off, c in recs:
-            n = len(c)
-            nx, ny, _ = g.dims[o]
-            idx = c["idx"].astype(np.int64)
-            sl = slice(pos, pos + n)
-            out["o"][sl] = o
-            out["s"][sl] = c["tag"] % g.ngl - 1
-            out["x"][sl] = idx % nx
-            out["y"][sl] = (idx // nx) % ny
-            out["z"][sl] = idx // (nx * ny) + off
-            out["val"][sl] = c["val"]
-            pos += n
+        out["o"] = oct_
+        out["s"] = local["tag"] % g.ngl - 1
+        out["x"] = idx % nxv
+        out["y"] = (idx // nxv) % nyv
+        out["z"] = idx // (nxv * nyv) + offs[oct_]
+        out["val"] = local["val"]
         out["keep"] = keep
         out["R"] = R
         parts = self._allgather_records(out)
         # global order: (o, s) major, then ranks in slab order (their z ranges are disjoint
         # and ascending), each rank's list already in (z, y, x) order
         if self.world > 1:
-            chunks = []
-            for o in range(g.num_octaves):
-                for s in range(g.K):
-                    for p in parts:
-                        m = (p["o"] == o) & (p["s"] == s)
-                        chunks.append(p[m])
+            # every rank's list is sorted by (o, s): cut it at the (o, s) boundaries
+            nkey = g.num_octaves * g.K
+            cuts = [np.searchsorted(p["o"].astype(np.int64) * g.K + p["s"], np.arange(nkey + 1))
+                    for p in parts]
+            chunks = [p[c[k]:c[k + 1]] for k in range(nkey) for p, c in zip(parts, cuts)]
             allc = np.concatenate(chunks) if chunks else out
         else:
             allc = out
@@ -499,7 +549,8 @@ class ShardedSift3D:
         kp = np.zeros(len(kept), KP_DTYPE)
         kp["o"], kp["s"] = kept["o"], kept["s"]
         kp["xd"], kp["yd"], kp["zd"] = kept["x"], kept["y"], kept["z"]
-        kp["sd"] = [self._scale(int(o), int(s)) for o, s in zip(kept["o"], kept["s"])]
+        sd_tab = np.array([[self._scale(o, s) for s in range(g.K)] for o in range(g.num_octaves)])
+        kp["sd"] = sd_tab[kept["o"], kept["s"]] if len(kept) else 0.0
         kp["R"] = kept["R"].reshape(-1, 3, 3)
         # copy_Keypoint omits `strength` (sift.c:372-384): slot j keeps candidate j's (Q2)
         kp["strength"] = allc["val"][:len(kept)]

@@ -98,6 +98,12 @@ class OracleBackend:
     def level_table(self, levels):
         return levels
 
+    def extrema_orient(self, specs, table, peak, corner):
+        recs = [self.extrema(lv, nx, ny, nz, peak) for lv, nx, ny, nz in specs]
+        local = np.concatenate(recs) if recs else np.zeros(0, CAND_DTYPE)
+        R, keep = self.orient(table, local, corner)
+        return local, R, keep
+
     def orient(self, table, cands, corner):
         n = len(cands)
         R = np.zeros((n, 9), np.float32)
