@@ -29,6 +29,8 @@ def run(n=512, reps=3):
         for ax in range(3):
             for _ in range(reps):
                 hip.fir(src, dst, ax, taps)
+        for _ in range(reps):
+            hip.fir_yz(src, dst, taps)
     torch.cuda.synchronize()
 
 
@@ -54,11 +56,10 @@ def parse(fetch_dir, write_dir, n=512):
         w = wr.get((k, gx), [0.0])
         fetch_b = 2.0 * 1024.0 * sum(v) / len(v)
         write_b = 1024.0 * sum(w) / len(w)
+        alg = (16 if "yz" in k else 8) * n ** 3
         res[k] = dict(fetch_bytes=round(fetch_b), write_bytes=round(write_b),
-                                             hbm_bytes=round(fetch_b + write_b),
-                                             algorithmic_bytes=8 * n ** 3,
-                                             ratio=round((fetch_b + write_b) / (8.0 * n ** 3), 3),
-                                             dispatches=len(v))
+                      hbm_bytes=round(fetch_b + write_b), algorithmic_bytes=alg,
+                      ratio=round((fetch_b + write_b) / float(alg), 3), dispatches=len(v))
     return res
 
 
