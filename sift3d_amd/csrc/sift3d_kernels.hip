@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void k_fir_sweep_u1(FirParams P, SweepGeom G, 
 template <int HW, int TY>
 __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(1, 4))) void k_fir_yz_u1(FirParams P, FirTaps T, EdgeTab Ey, EdgeTab Ez)
 {
-    constexpr int W = 2 * HW + 1, TXQ = 16, ROWS = TY + 2 * HW, NT = TXQ * TY;
+    constexpr int W = 2 * HW + 1, TXQ = 16, ROWS = TY + 2 * HW;
     __shared__ float4 tile[2][ROWS][TXQ];
     const int tid = threadIdx.x;
     const int qx = tid % TXQ, ty = tid / TXQ;
@@ -653,21 +653,54 @@ __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(1, 4)))
         }
         return ld4(s + (size_t)i * nx);
     };
-    // y-filtered value of this thread's column in local plane pl (block-wide call)
-    auto yfilt = [&](int pl) -> float4 {
+    // Tile rows of one plane held in registers: every thread stages row ty and, for the first
+    // 2*HW rows of threads, row ty + TY.  For HW <= 5 they are fetched ONE PLANE AHEAD (the
+    // `hint` of yfilt), so the global-load latency overlaps the FIR arithmetic of the current
+    // plane; wider filters have no registers to spare for that (occupancy would drop).
+    static_assert(2 * HW <= TY, "two tile rows per thread");
+    constexpr bool PF = HW <= 5;
+    float4 pr0 = make_float4(0.f, 0.f, 0.f, 0.f), pr1 = pr0;
+    int pre_pl = -(1 << 30);
+    const bool second = ty + TY < ROWS;
+    auto fetch = [&](int pl) {
+        pr0 = ext_y(pl, y0 - HW + ty);
+        if (second)
+            pr1 = ext_y(pl, y0 - HW + ty + TY);
+        pre_pl = pl;
+    };
+    // y-filtered value of this thread's column in local plane pl (block-wide call); `hint` is
+    // the plane the next call will ask for (or < 0)
+    auto yfilt = [&](int pl, int hint) -> float4 {
         pl = clampi(pl, 0, nl1);
-        for (int r = tid; r < ROWS * TXQ; r += NT) {
-            // r -> (row, quad) with quad == qx because NT is a multiple of TXQ
-            const int row = r / TXQ;
-            tile[buf][row][qx] = ext_y(pl, y0 - HW + row);
+        if (PF) {
+            if (pre_pl != pl)                   // block-uniform
+                fetch(pl);
+            tile[buf][ty][qx] = pr0;
+            if (second)
+                tile[buf][ty + TY][qx] = pr1;
+        } else {
+            // r -> (row, quad) with quad == qx because the block size is a multiple of TXQ
+            for (int r = tid; r < ROWS * TXQ; r += TXQ * TY)
+                tile[buf][r / TXQ][qx] = ext_y(pl, y0 - HW + r / TXQ);
         }
         __syncthreads();
+        if (PF && hint >= 0)
+            fetch(clampi(hint, 0, nl1));
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int dd = -HW; dd <= HW; dd++)
             Vec<4>::mac(acc, T.k[dd + HW], tile[buf][ty + HW - dd][qx]);
         buf ^= 1;   // the next plane is staged in the other buffer: one barrier per plane
         return acc;
+    };
+    // first plane that ext_z(r) will request (-1: none)
+    auto first_plane = [&](int r) -> int {
+        const int i = r + off;
+        if (i < 0)
+            return -i - off;
+        if (i >= endz)
+            return i - endz > HW ? -1 : Ez.lo[i - endz] - off;
+        return r;
     };
     // extended-z plane i (LOCAL index r = i - off may be outside the slab at global faces):
     // one or two y-filtered planes, selected with block-uniform scalars so that yfilt has a
@@ -689,10 +722,11 @@ __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(1, 4)))
                 np = 2;
             }
         }
+        const int nxt = PF ? first_plane(r + 1) : -1;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
 #pragma unroll 1
         for (int k = 0; k < np; k++) {
-            const float4 yv = yfilt(pa + k);
+            const float4 yv = yfilt(pa + k, k + 1 < np ? pa + k + 1 : nxt);
             if (k == 0)
                 a = yv;
             else
@@ -1892,12 +1926,14 @@ static bool launch_fir_dy_hw(const FirParams &P, const SweepGeom &G, const FirTa
 
 template <int HW>
 static void launch_fir_yz(const FirParams &P, const FirTaps &T, const EdgeTab &Ey, const EdgeTab &Ez,
-                          hipStream_t st)
+                          int ty, hipStream_t st)
 {
-    constexpr int TY = 32;
     const int nseg = (P.z_hi - P.z_lo + P.ts - 1) / P.ts;
-    dim3 grid((P.nx / 4 + 15) / 16, (P.ny + TY - 1) / TY, nseg);
-    hipLaunchKernelGGL((k_fir_yz_u1<HW, TY>), grid, dim3(16 * TY), 0, st, P, T, Ey, Ez);
+    dim3 grid((P.nx / 4 + 15) / 16, (P.ny + ty - 1) / ty, nseg);
+    if (ty == 32)
+        hipLaunchKernelGGL((k_fir_yz_u1<HW, 32>), grid, dim3(16 * 32), 0, st, P, T, Ey, Ez);
+    else
+        hipLaunchKernelGGL((k_fir_yz_u1<HW, 16>), grid, dim3(16 * 16), 0, st, P, T, Ey, Ez);
 }
 
 static bool is_dyadic(float uf, int *shift)
@@ -2074,9 +2110,12 @@ int sift3d_hip_fir_yz_u1(const float *d_src, float *d_dst, int nx, int ny, int n
     P.nx = nx; P.ny = ny; P.nz = nz;
     P.axis = 2; P.hw = hw; P.uf = 1.0f; P.uhw = hw;
     P.n_glob = n_glob; P.off = off; P.z_lo = z_lo; P.z_hi = z_hi;
+    // tile height: 32 rows measured best for every width (16 selectable for experiments)
+    static const int ty_env = getenv("SIFT3D_AMD_YZ_TY") ? atoi(getenv("SIFT3D_AMD_YZ_TY")) : 0;
+    const int ty = ty_env == 16 || ty_env == 32 ? ty_env : 32;
     {
         // z segmentation: >= 4096 waves in flight, segments of at least 32 planes
-        const long blocks_xy = (long)((nx / 4 + 15) / 16) * ((ny + 31) / 32);
+        const long blocks_xy = (long)((nx / 4 + 15) / 16) * ((ny + ty - 1) / ty) * ty / 32;
         const int n_out = z_hi - z_lo;
         long want = (512 + blocks_xy - 1) / blocks_xy;
         long cap = n_out / 32 > 1 ? n_out / 32 : 1;
@@ -2087,14 +2126,14 @@ int sift3d_hip_fir_yz_u1(const float *d_src, float *d_dst, int nx, int ny, int n
     }
     const EdgeTab Ey = edge_table(ny, hw), Ez = edge_table(n_glob, hw);
     switch (hw) {
-    case 1: launch_fir_yz<1>(P, T, Ey, Ez, st); break;
-    case 2: launch_fir_yz<2>(P, T, Ey, Ez, st); break;
-    case 3: launch_fir_yz<3>(P, T, Ey, Ez, st); break;
-    case 4: launch_fir_yz<4>(P, T, Ey, Ez, st); break;
-    case 5: launch_fir_yz<5>(P, T, Ey, Ez, st); break;
-    case 6: launch_fir_yz<6>(P, T, Ey, Ez, st); break;
-    case 7: launch_fir_yz<7>(P, T, Ey, Ez, st); break;
-    default: launch_fir_yz<8>(P, T, Ey, Ez, st); break;
+    case 1: launch_fir_yz<1>(P, T, Ey, Ez, ty, st); break;
+    case 2: launch_fir_yz<2>(P, T, Ey, Ez, ty, st); break;
+    case 3: launch_fir_yz<3>(P, T, Ey, Ez, ty, st); break;
+    case 4: launch_fir_yz<4>(P, T, Ey, Ez, ty, st); break;
+    case 5: launch_fir_yz<5>(P, T, Ey, Ez, ty, st); break;
+    case 6: launch_fir_yz<6>(P, T, Ey, Ez, ty, st); break;
+    case 7: launch_fir_yz<7>(P, T, Ey, Ez, ty, st); break;
+    default: launch_fir_yz<8>(P, T, Ey, Ez, ty, st); break;
     }
     LAUNCH_CHECK();
     return SIFT3D_SUCCESS;
