@@ -1430,21 +1430,36 @@ static_assert(sizeof(FaceRec) == SIFT3D_HIP_FACE_FLOATS * 4, "face record layout
 // per-face constants as the kernel wants them: e1, e2, t, q, e2.q (+3 pad) = 16 floats
 __constant__ float c_face16[20 * 16];
 __constant__ int c_face_idx[60];   // unswapped vertex ids of each face (bins, quirk Q1)
+__constant__ int c_bin_off[12];    // LDS offset of each vertex's 64-cell block (see k_describe)
 __constant__ float c_verts[12 * 3];// unit vertices
 __constant__ int c_vert_faces[12 * 5]; // the five faces around each vertex, ascending
 
 constexpr int DQ = 256; // compaction queue length (power of two, >= 3 * 64)
+// LDS histogram: bin (cell, vertex) lives at c_bin_off[vertex] + cell, cell = ix + 4*iy + 16*iz.
+// The offsets are 64*rank + {0, 8, 18, 26}[colour] for a proper 4-colouring of the
+// icosahedron's vertices, which puts the 24 bins of any voxel (8 neighbouring cells x the 3
+// vertices of a face) on 24 different banks of the 32 that ds_read_b32/ds_write_b32 use.
+constexpr int HIST_LDS = 800;
+// record rows: voxel v of a batch sits at (v & 1) * 48 + (v >> 1) -- even voxels (first commit
+// half-wave) from 0, odd ones from 48, so both the 64-lane writes of phase A and the 16-byte
+// reads of phase B are conflict-free with a row stride of 84 floats
+constexpr int RROW = 84, RODD = 48;
 
 __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restrict__ levels,
                                                  const sift3d_hip_kp *__restrict__ kps, uint32_t n,
                                                  float *__restrict__ out, int ablate)
 {
-    __shared__ float hist[768];
+    __shared__ float hist[HIST_LDS];
     __shared__ __attribute__((aligned(16))) float sface[20 * 16];
-    __shared__ float mw[8][65];   // mag * trilinear weight of the eight cells
-    __shared__ float bw[3][65];   // barycentric weights
-    __shared__ int meta[64];      // cell base bin | corner validity<<10 | bin0<<18 | bin1<<22 | bin2<<26
+    // Phase A -> phase B records of the batch's 64 voxels, each commit half-wave reading ITS
+    // voxels contiguously
+    __shared__ __attribute__((aligned(16))) float mw[8][RROW]; // mag * trilinear weight of the eight cells
+    __shared__ __attribute__((aligned(16))) float bw[3][RROW]; // barycentric weights
+    __shared__ __attribute__((aligned(16))) int meta0[RROW];   // base cell | corner validity << 6
+    __shared__ __attribute__((aligned(16))) int meta1[RROW];   // bin offsets of the face's three vertices, 10 bits each
+    __shared__ uint64_t sexp[32]; // s3d_exp2_tab
     __shared__ int svf[12];       // the five faces around each vertex, 5 bits each
+    __shared__ int svm[12];       // the same as a 20-bit face mask
     __shared__ int queue[DQ];     // xx | yy<<10 | zz<<20, window-relative, in scan order
     const uint32_t ki = blockIdx.x;
     if (ki >= n)
@@ -1452,7 +1467,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     const int lane = threadIdx.x;
     const sift3d_hip_kp K = kps[ki];
     const sift3d_hip_level L = levels[K.level];
-    for (int i = lane; i < 768; i += 64)
+    for (int i = lane; i < HIST_LDS; i += 64)
         hist[i] = 0.0f;
     for (int i = lane; i < 320; i += 64)
         sface[i] = c_face16[i];
@@ -1460,6 +1475,12 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
         svf[lane] = c_vert_faces[lane * 5] | (c_vert_faces[lane * 5 + 1] << 5) |
                     (c_vert_faces[lane * 5 + 2] << 10) | (c_vert_faces[lane * 5 + 3] << 15) |
                     (c_vert_faces[lane * 5 + 4] << 20);
+    if (lane < 12)
+        svm[lane] = (1 << c_vert_faces[lane * 5]) | (1 << c_vert_faces[lane * 5 + 1]) |
+                    (1 << c_vert_faces[lane * 5 + 2]) | (1 << c_vert_faces[lane * 5 + 3]) |
+                    (1 << c_vert_faces[lane * 5 + 4]);
+    if (lane < 32)
+        sexp[lane] = s3d_exp2_tab[lane];
 
     const float sigma = (float)(K.sd * 7.071067812);                  // sift.c:1453
     const float rad = (float)(2.0 * (double)sigma);                   // sift.c:1454
@@ -1479,10 +1500,12 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     // phase B roles: lanes 0..23 commit the first voxel of a pair, lanes 32..55 the second;
     // each committer lane is one (trilinear cell corner, face vertex) pair
     const int half = lane >> 5, l5 = lane & 31;
-    const int pc = l5 / 3, pj = l5 - 3 * pc;
-    const int pdx = (pc >> 2) & 1, pdy = (pc >> 1) & 1, pdz = pc & 1;
-    const int coff = (pdx + 4 * pdy + 16 * pdz) * 12;  // bin offset of this lane's cell corner
     const bool committer = l5 < 24;
+    const int pc = committer ? l5 / 3 : 0, pj = committer ? l5 - 3 * pc : 0;
+    const int slot = (lane & 1) * RODD + (lane >> 1);  // where phase A puts this lane's voxel
+    const int pdx = (pc >> 2) & 1, pdy = (pc >> 1) & 1, pdz = pc & 1;
+    const int coff = pdx + 4 * pdy + 16 * pdz;         // cell offset of this lane's corner
+    const int on_bit = committer ? 64 << pc : 0;       // its validity bit in meta0
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     __syncthreads();
 
@@ -1537,7 +1560,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
             gx *= 1.0f / L.ux;
             gy *= 1.0f / L.uy;
             gz *= 1.0f / L.uz;
-            const float w = s3d_expf(-0.5f * sq / sig2);           // sift.c:1498
+            const float w = s3d_expf_with(-0.5f * sq / sig2, sexp); // sift.c:1498
             gx = gx * w; gy = gy * w; gz = gz * w;
             const float rx = R[0] * gx + R[3] * gy + R[6] * gz;    // sift.c:1502
             const float ry = R[1] * gx + R[4] * gy + R[7] * gz;
@@ -1545,45 +1568,91 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
             const float m2 = rx * rx + ry * ry + rz * rz;
             if (!(m2 < 1.1920928955078125e-06f)) {                 // sift.c:1264
                 // icos_hist_bin (sift.c:1268-1286): the first face in table order whose
-                // barycentrics are >= -eps wins.  Every face that can pass contains the
-                // icosahedron vertex nearest to the ray (its Voronoi cell is made of thirds
-                // of its five faces, and eps << the cell margins), so only those five are
-                // evaluated -- in ascending face order, with cart2bary's arithmetic.
-                int vs = 0;
-                float best = rx * c_verts[0] + ry * c_verts[1] + rz * c_verts[2];
-#pragma unroll
-                for (int v = 1; v < 12; v++) {
-                    const float dp = rx * c_verts[3 * v] + ry * c_verts[3 * v + 1] + rz * c_verts[3 * v + 2];
-                    if (dp > best) { best = dp; vs = v; }
-                }
-                int face = -1;
+                // barycentrics are >= -eps wins.  A face can only pass if the ray hits it or
+                // misses it by ~eps, so the candidates are the two faces on the edge between the
+                // two icosahedron vertices nearest to the ray (ascending order, cart2bary's
+                // arithmetic).  Within ~1e-3 rad of a vertex -- where more than two faces are
+                // within eps -- and whenever that shortcut finds nothing, all five faces
+                // around the nearest vertex are tried instead.
+                //
+                // Nearest two vertices: the vertices are (0,+-1,+-g), (+-1,+-g,0), (+-g,0,+-1)
+                // (ids 0-3, 4-7, 8-11; bit 0 / bit 1 of the id = sign of the first / second
+                // non-zero coordinate), so the best vertex of a family has the ray's signs and
+                // its runner-up flips the sign of the smaller term.
+                const float gr = 1.6180339887f;
+                const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
+                const float hx = gr * ax, hy = gr * ay, hz = gr * az;
+                const int sxn = rx < 0.0f, syn = ry < 0.0f, szn = rz < 0.0f;
+                const float s0 = ay + hz, s1 = ax + hy, s2 = hx + az;
+                const int i0 = syn + 2 * szn, i1 = 4 + sxn + 2 * syn, i2 = 8 + sxn + 2 * szn;
+                const float f0 = s0 - 2.0f * fminf(ay, hz), f1 = s1 - 2.0f * fminf(ax, hy),
+                            f2 = s2 - 2.0f * fminf(hx, az);
+                const int a0 = i0 ^ (ay <= hz ? 1 : 2), a1 = i1 ^ (ax <= hy ? 1 : 2),
+                          a2 = i2 ^ (hx <= az ? 1 : 2);
+                const bool b01 = s0 >= s1;
+                const float t = b01 ? s0 : s1, l = b01 ? s1 : s0, tf = b01 ? f0 : f1;
+                const int ti = b01 ? i0 : i1, li = b01 ? i1 : i0, ta = b01 ? a0 : a1;
+                const bool bt = t >= s2;
+                const int vs = bt ? ti : i2;                       // nearest vertex
+                const float best = bt ? t : s2;
+                // runner-up: best of (other families' winners, the winner family's flip)
+                float c1 = bt ? l : t, c2 = bt ? s2 : f2, c3 = bt ? tf : -1.0f;
+                int d1 = bt ? li : ti, d2 = bt ? i2 : a2, d3 = bt ? ta : 0;
+                if (c2 > c1) { c1 = c2; d1 = d2; }
+                if (c3 > c1) { c1 = c3; d1 = d3; }
+                const int vs2 = d1;
+
+                int face = -1, fidx = 0;
                 float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-                const int five = svf[vs];
-#pragma unroll 1
-                for (int k = 0; k < 5; k++) {
-                    const int f = (five >> (5 * k)) & 31;
+                auto eval = [&](int f, float &xb, float &yb, float &zb, int &fi) -> bool {
                     const float4 A0 = *reinterpret_cast<const float4 *>(&sface[f * 16]);
                     const float4 A1 = *reinterpret_cast<const float4 *>(&sface[f * 16 + 4]);
                     const float4 A2 = *reinterpret_cast<const float4 *>(&sface[f * 16 + 8]);
                     const float4 A3 = *reinterpret_cast<const float4 *>(&sface[f * 16 + 12]);
                     // e1 = A0.xyz, e2 = (A0.w, A1.x, A1.y), t = (A1.z, A1.w, A2.x),
-                    // q = (A2.y, A2.z, A2.w), e2.q = A3.x
+                    // q = (A2.y, A2.z, A2.w), e2.q = A3.x, bin offsets = A3.y
                     const float px = ry * A1.y - rz * A1.x;        // p = g x e2, sift.c:278
                     const float py = rz * A0.w - rx * A1.y;
                     const float pz = rx * A1.x - ry * A0.w;
                     const float det = A0.x * px + A0.y * py + A0.z * pz;
-                    if (fabsf(det) < 1.1920928955078125e-06f)      // sift.c:282
-                        continue;
                     const float di = 1.0f / det;
-                    const float yb = di * (A1.z * px + A1.w * py + A2.x * pz);
-                    const float zb = di * (rx * A2.y + ry * A2.z + rz * A2.w);
-                    const float xb = 1.0f - yb - zb;
+                    yb = di * (A1.z * px + A1.w * py + A2.x * pz);
+                    zb = di * (rx * A2.y + ry * A2.z + rz * A2.w);
+                    xb = 1.0f - yb - zb;
                     const float kk = A3.x * di;
-                    if (xb < -1.1920928955078125e-06f || yb < -1.1920928955078125e-06f ||
-                        zb < -1.1920928955078125e-06f || kk < 0)   // sift.c:1277-1279
-                        continue;
-                    face = f; b0 = xb; b1 = yb; b2 = zb;
-                    break;
+                    fi = __float_as_int(A3.y);
+                    return !(fabsf(det) < 1.1920928955078125e-06f) &&            // sift.c:282
+                           !(xb < -1.1920928955078125e-06f || yb < -1.1920928955078125e-06f ||
+                             zb < -1.1920928955078125e-06f || kk < 0);            // sift.c:1277-1279
+                };
+                const int pairm = svm[vs] & svm[vs2];
+                // cos^2 of the angle to the nearest vertex > 1 - 2e-6  (|vertex|^2 = 1 + g^2)
+                bool slow = __popc(pairm) != 2 || best * best > m2 * (3.6180339887f * (1.0f - 2e-6f));
+                if (!slow) {
+                    const int fa = __ffs(pairm) - 1, fb = __ffs(pairm & (pairm - 1)) - 1;
+                    float xa, ya, za, xc, yc, zc;
+                    int ia, ic;
+                    const bool pa = eval(fa, xa, ya, za, ia), pb = eval(fb, xc, yc, zc, ic);
+                    if (pa) {
+                        face = fa; b0 = xa; b1 = ya; b2 = za; fidx = ia;
+                    } else if (pb) {
+                        face = fb; b0 = xc; b1 = yc; b2 = zc; fidx = ic;
+                    } else {
+                        slow = true;
+                    }
+                }
+                if (slow) {
+                    const int five = svf[vs];
+#pragma unroll 1
+                    for (int k = 0; k < 5; k++) {
+                        const int f = (five >> (5 * k)) & 31;
+                        float xb, yb, zb;
+                        int fi;
+                        if (eval(f, xb, yb, zb, fi)) {
+                            face = f; b0 = xb; b1 = yb; b2 = zb; fidx = fi;
+                            break;
+                        }
+                    }
                 }
                 if (face >= 0) {
                     ok = true;
@@ -1597,9 +1666,9 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                     for (int c = 0; c < 8; c++) {
                         // weight = wx * wy * wz (sift.c:1361-1363); value = mag * weight * bary
                         const float wt = ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1];
-                        mw[c][lane] = mag * wt;
+                        mw[c][slot] = mag * wt;
                     }
-                    bw[0][lane] = b0; bw[1][lane] = b1; bw[2][lane] = b2;
+                    bw[0][slot] = b0; bw[1][slot] = b1; bw[2][slot] = b2;
                     // commit record: base bin of cell (ix,iy,iz), validity of the 8 trilinear
                     // corners (sift.c:1349-1352), and the three vertex bins -- addressed through
                     // the UNSWAPPED idx[] of the face (quirk Q1)
@@ -1609,14 +1678,13 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                     for (int c = 0; c < 8; c++)
                         valid |= ((ix + ((c >> 2) & 1) < 4) && (iy + ((c >> 1) & 1) < 4) &&
                                   (iz + (c & 1) < 4)) ? (1 << c) : 0;
-                    meta[lane] = ((ix + 4 * iy + 16 * iz) * 12) | (valid << 10) |
-                                 (c_face_idx[face * 3] << 18) | (c_face_idx[face * 3 + 1] << 22) |
-                                 (c_face_idx[face * 3 + 2] << 26);
+                    meta0[slot] = (ix + 4 * iy + 16 * iz) | (valid << 6);
+                    meta1[slot] = fidx;
                 }
             }
         }
         if (!ok)
-            meta[lane] = 0;            // no valid corner -> nothing is committed for this voxel
+            meta0[slot] = 0;           // no valid corner -> nothing is committed for this voxel
         __syncthreads();
         // Ordered commit, two voxels per iteration (2i by lanes 0..23, 2i+1 by lanes 32..55).
         // 24 lanes per voxel (8 cells x 3 face vertices) each own one distinct histogram bin,
@@ -1624,23 +1692,38 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
         // issued before the second's and a wave's DS operations execute in issue order, so every
         // bin receives its contributions in the reference's voxel order (sift.c:1340-1373) and
         // the float sums are bit-identical.  (LDS float atomics would also be ordered but retire
-        // < 1 lane-add/clk/CU.)  Fully unrolled: all LDS addresses are base + immediate.
+        // < 1 lane-add/clk/CU.)  The records of four iterations are read with three 16-byte
+        // loads, one chunk ahead of the dependent RMW chain.
         if (!(ablate & 1)) {
+            const int hb = half * RODD;
+            int4 ma4 = *reinterpret_cast<const int4 *>(&meta0[hb]);
+            int4 mb4 = *reinterpret_cast<const int4 *>(&meta1[hb]);
+            float4 mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb]);
+            float4 bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb]);
 #pragma unroll
-            for (int i = 0; i < 32; i++) {
-                const int v = 2 * i + half;
-                const int mt = meta[v];
-                const bool on = committer && ((mt >> (10 + pc)) & 1);         // sift.c:1349-1352
-                const int addr = (mt & 1023) + coff + ((mt >> (18 + 4 * pj)) & 15);
-                const float val = mw[pc][v] * bw[pj][v];                      // sift.c:1371-1373
-                if (half == 0 && on)
-                    hist[addr] = hist[addr] + val;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (half == 1 && on)
-                    hist[addr] = hist[addr] + val;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+            for (int c = 0; c < 8; c++) {
+                const int ma[4] = { ma4.x, ma4.y, ma4.z, ma4.w }, mb[4] = { mb4.x, mb4.y, mb4.z, mb4.w };
+                const float mv[4] = { mw4.x, mw4.y, mw4.z, mw4.w }, bv[4] = { bw4.x, bw4.y, bw4.z, bw4.w };
+                if (c < 7) {
+                    ma4 = *reinterpret_cast<const int4 *>(&meta0[hb + 4 * c + 4]);
+                    mb4 = *reinterpret_cast<const int4 *>(&meta1[hb + 4 * c + 4]);
+                    mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb + 4 * c + 4]);
+                    bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb + 4 * c + 4]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool on = (ma[u] & on_bit) != 0;                         // sift.c:1349-1352
+                    const int addr = (ma[u] & 63) + coff + ((mb[u] >> (10 * pj)) & 1023);
+                    const float val = mv[u] * bv[u];                               // sift.c:1371-1373
+                    if (half == 0 && on)
+                        hist[addr] = hist[addr] + val;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (half == 1 && on)
+                        hist[addr] = hist[addr] + val;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
         __syncthreads();
@@ -1700,19 +1783,21 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     }
     __syncthreads();
     // normalize_desc -> clamp -> normalize_desc (sift.c:1402-1429, 1514-1526).  The double
-    // sum runs in element order on every lane (uniform), as in the reference.
+    // sum runs in element order (bin = cell * 12 + vertex) on every lane (uniform), as in the
+    // reference.
     const float trunc = 0.2f * 128.0f / 768.0f;                               // sift.c:45
     for (int pass = 0; pass < 2; pass++) {
         double norm = 0.0;
-        for (int i = 0; i < 768; i++) {
-            const float el = hist[i];
-            norm += (double)el * (double)el;
-        }
+        for (int cell = 0; cell < 64; cell++)
+            for (int v = 0; v < 12; v++) {
+                const float el = hist[c_bin_off[v] + cell];
+                norm += (double)el * (double)el;
+            }
         norm = sqrt(norm) + 2.220446049250313e-16;                            // DBL_EPSILON
         const float inv = (float)(1.0 / norm);                                // 1.0f / norm
         __syncthreads();
-        for (int i = lane; i < 768; i += 64) {
-            float el = hist[i] * inv;
+        for (int i = lane; i < HIST_LDS; i += 64) {
+            float el = hist[i] * inv;                                         // unused slots hold 0
             if (pass == 0)
                 el = el < trunc ? el : trunc;                                 // sift.c:1520
             hist[i] = el;
@@ -1720,7 +1805,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
         __syncthreads();
     }
     for (int i = lane; i < 768; i += 64)
-        out[(size_t)ki * 768 + i] = hist[i];
+        out[(size_t)ki * 768 + i] = hist[c_bin_off[i % 12] + i / 12];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2259,6 +2344,55 @@ int sift3d_hip_set_mesh(const float *faces)
             snprintf(g_err, sizeof(g_err), "sift3d_hip_set_mesh: vertex %d has %d faces", v, cnt[v]);
             return SIFT3D_FAILURE;
         }
+    // Proper 4-colouring of the vertex graph (backtracking over 12 vertices), then the LDS
+    // offset of each vertex's 64-cell block: blocks sorted by colour, 64 floats apart, shifted
+    // by {0, 8, 18, 26} per colour -- see HIST_LDS in the kernel section.
+    int colour[12], binoff[12];
+    {
+        bool adj[12][12];
+        memset(adj, 0, sizeof(adj));
+        for (int f = 0; f < 20; f++)
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++)
+                    if (a != b)
+                        adj[idx[f * 3 + a]][idx[f * 3 + b]] = true;
+        for (int v = 0; v < 12; v++)
+            colour[v] = -1;
+        int v = 0;
+        while (v >= 0 && v < 12) {
+            int c = colour[v] + 1;
+            for (; c < 4; c++) {
+                bool clash = false;
+                for (int u = 0; u < v; u++)
+                    clash = clash || (adj[v][u] && colour[u] == c);
+                if (!clash)
+                    break;
+            }
+            if (c < 4) {
+                colour[v++] = c;
+            } else {
+                colour[v--] = -1;
+            }
+        }
+        if (v < 0) {
+            snprintf(g_err, sizeof(g_err), "sift3d_hip_set_mesh: vertex graph is not 4-colourable");
+            return SIFT3D_FAILURE;
+        }
+        static const int shift[4] = { 0, 8, 18, 26 };
+        int rank = 0;
+        for (int c = 0; c < 4; c++)
+            for (int u = 0; u < 12; u++)
+                if (colour[u] == c)
+                    binoff[u] = 64 * rank++ + shift[c];
+    }
+    for (int f = 0; f < 20; f++) {
+        // slot 13 of the face record: LDS bin offsets of the face's three UNSWAPPED vertex ids
+        // (the bins, quirk Q1), 10 bits each
+        const int packed = binoff[idx[f * 3]] | (binoff[idx[f * 3 + 1]] << 10) |
+                           (binoff[idx[f * 3 + 2]] << 20);
+        memcpy(f16 + f * 16 + 13, &packed, sizeof(int));
+    }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_bin_off), binoff, sizeof(binoff)));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_face16), f16, sizeof(f16)));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_face_idx), idx, sizeof(idx)));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_verts), verts, sizeof(verts)));

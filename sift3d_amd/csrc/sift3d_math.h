@@ -68,7 +68,7 @@ S3D_HD uint64_t s3d_f64_as_u64(double d)
  * limits (0 / +inf) are returned without libm's errno/fenv side effects.
  * `use_fma` selects the contraction pattern of glibc's FMA-enabled build
  * (what an x86-64 host with FMA3 dispatches to). */
-S3D_HD float s3d_expf_impl(float x, int use_fma)
+S3D_HD float s3d_expf_tab(float x, int use_fma, const uint64_t *tab)
 {
     const double inv_ln2_n = 0x1.71547652b82fep+0 * 32.0;
     const double shift = 0x1.8p+52;
@@ -88,7 +88,7 @@ S3D_HD float s3d_expf_impl(float x, int use_fma)
     ki = s3d_f64_as_u64(kd);
     kd -= shift;
     r = z - kd;
-    t = s3d_exp2_tab[ki % 32];
+    t = tab[ki % 32];
     t += ki << (52 - 5);
     s = s3d_u64_as_f64(t);
     if (use_fma) {
@@ -106,11 +106,16 @@ S3D_HD float s3d_expf_impl(float x, int use_fma)
     return (float)y;
 }
 
+S3D_HD float s3d_expf_impl(float x, int use_fma) { return s3d_expf_tab(x, use_fma, s3d_exp2_tab); }
+
 #ifndef S3D_EXPF_FMA
 #define S3D_EXPF_FMA 1
 #endif
 
 S3D_HD float s3d_expf(float x) { return s3d_expf_impl(x, S3D_EXPF_FMA); }
+
+/* same, with the caller's copy of s3d_exp2_tab (the kernels keep one in LDS) */
+S3D_HD float s3d_expf_with(float x, const uint64_t *tab) { return s3d_expf_tab(x, S3D_EXPF_FMA, tab); }
 
 /* 3x3 symmetric eigen-decomposition, upper triangle of row-major A is read.
  * L ascending; eigenvector j is column j of row-major Q. */
