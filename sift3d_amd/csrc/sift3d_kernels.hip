@@ -1433,8 +1433,10 @@ __constant__ int c_face_idx[60];   // unswapped vertex ids of each face (bins, q
 __constant__ int c_bin_off[12];    // LDS offset of each vertex's 64-cell block (see k_describe)
 __constant__ float c_verts[12 * 3];// unit vertices
 __constant__ int c_vert_faces[12 * 5]; // the five faces around each vertex, ascending
+__constant__ int c_vf5[12];        // the same, 5 bits per face
+__constant__ int c_vmask[12];      // the same, as a 20-bit face mask
 
-constexpr int DQ = 256; // compaction queue length (power of two, >= 3 * 64)
+constexpr int DQ = 128; // compaction queue length (power of two, >= 2 * 64)
 // LDS histogram: bin (cell, vertex) lives at c_bin_off[vertex] + cell, cell = ix + 4*iy + 16*iz.
 // The offsets are 64*rank + {0, 8, 18, 26}[colour] for a proper 4-colouring of the
 // icosahedron's vertices, which puts the 24 bins of any voxel (8 neighbouring cells x the 3
@@ -1445,21 +1447,17 @@ constexpr int HIST_LDS = 800;
 // reads of phase B are conflict-free with a row stride of 84 floats
 constexpr int RROW = 84, RODD = 48;
 
-__global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restrict__ levels,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_describe(const sift3d_hip_level *__restrict__ levels,
                                                  const sift3d_hip_kp *__restrict__ kps, uint32_t n,
                                                  float *__restrict__ out, int ablate)
 {
     __shared__ float hist[HIST_LDS];
-    __shared__ __attribute__((aligned(16))) float sface[20 * 16];
     // Phase A -> phase B records of the batch's 64 voxels, each commit half-wave reading ITS
     // voxels contiguously
     __shared__ __attribute__((aligned(16))) float mw[8][RROW]; // mag * trilinear weight of the eight cells
     __shared__ __attribute__((aligned(16))) float bw[3][RROW]; // barycentric weights
-    __shared__ __attribute__((aligned(16))) int meta0[RROW];   // base cell | corner validity << 6
-    __shared__ __attribute__((aligned(16))) int meta1[RROW];   // bin offsets of the face's three vertices, 10 bits each
-    __shared__ uint64_t sexp[32]; // s3d_exp2_tab
-    __shared__ int svf[12];       // the five faces around each vertex, 5 bits each
-    __shared__ int svm[12];       // the same as a 20-bit face mask
+    __shared__ __attribute__((aligned(16))) int meta0[RROW];   // validity of the eight cell corners, bit 6 + corner
+    __shared__ __attribute__((aligned(16))) int ab[3][RROW];   // byte address of bin (base cell, face vertex j) in hist
     __shared__ int queue[DQ];     // xx | yy<<10 | zz<<20, window-relative, in scan order
     const uint32_t ki = blockIdx.x;
     if (ki >= n)
@@ -1469,18 +1467,6 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     const sift3d_hip_level L = levels[K.level];
     for (int i = lane; i < HIST_LDS; i += 64)
         hist[i] = 0.0f;
-    for (int i = lane; i < 320; i += 64)
-        sface[i] = c_face16[i];
-    if (lane < 12)
-        svf[lane] = c_vert_faces[lane * 5] | (c_vert_faces[lane * 5 + 1] << 5) |
-                    (c_vert_faces[lane * 5 + 2] << 10) | (c_vert_faces[lane * 5 + 3] << 15) |
-                    (c_vert_faces[lane * 5 + 4] << 20);
-    if (lane < 12)
-        svm[lane] = (1 << c_vert_faces[lane * 5]) | (1 << c_vert_faces[lane * 5 + 1]) |
-                    (1 << c_vert_faces[lane * 5 + 2]) | (1 << c_vert_faces[lane * 5 + 3]) |
-                    (1 << c_vert_faces[lane * 5 + 4]);
-    if (lane < 32)
-        sexp[lane] = s3d_exp2_tab[lane];
 
     const float sigma = (float)(K.sd * 7.071067812);                  // sift.c:1453
     const float rad = (float)(2.0 * (double)sigma);                   // sift.c:1454
@@ -1504,7 +1490,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     const int pc = committer ? l5 / 3 : 0, pj = committer ? l5 - 3 * pc : 0;
     const int slot = (lane & 1) * RODD + (lane >> 1);  // where phase A puts this lane's voxel
     const int pdx = (pc >> 2) & 1, pdy = (pc >> 1) & 1, pdz = pc & 1;
-    const int coff = pdx + 4 * pdy + 16 * pdz;         // cell offset of this lane's corner
+    const int coff4 = 4 * (pdx + 4 * pdy + 16 * pdz);  // byte offset of this lane's cell corner
     const int on_bit = committer ? 64 << pc : 0;       // its validity bit in meta0
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     __syncthreads();
@@ -1560,7 +1546,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
             gx *= 1.0f / L.ux;
             gy *= 1.0f / L.uy;
             gz *= 1.0f / L.uz;
-            const float w = s3d_expf_with(-0.5f * sq / sig2, sexp); // sift.c:1498
+            const float w = s3d_expf(-0.5f * sq / sig2);           // sift.c:1498
             gx = gx * w; gy = gy * w; gz = gz * w;
             const float rx = R[0] * gx + R[3] * gy + R[6] * gz;    // sift.c:1502
             const float ry = R[1] * gx + R[4] * gy + R[7] * gz;
@@ -1605,10 +1591,10 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                 int face = -1, fidx = 0;
                 float b0 = 0.f, b1 = 0.f, b2 = 0.f;
                 auto eval = [&](int f, float &xb, float &yb, float &zb, int &fi) -> bool {
-                    const float4 A0 = *reinterpret_cast<const float4 *>(&sface[f * 16]);
-                    const float4 A1 = *reinterpret_cast<const float4 *>(&sface[f * 16 + 4]);
-                    const float4 A2 = *reinterpret_cast<const float4 *>(&sface[f * 16 + 8]);
-                    const float4 A3 = *reinterpret_cast<const float4 *>(&sface[f * 16 + 12]);
+                    // (the tables stay in constant memory: LDS is what limits the number of
+                    // keypoints in flight per CU)
+                    const float4 *fr = reinterpret_cast<const float4 *>(c_face16) + f * 4;
+                    const float4 A0 = fr[0], A1 = fr[1], A2 = fr[2], A3 = fr[3];
                     // e1 = A0.xyz, e2 = (A0.w, A1.x, A1.y), t = (A1.z, A1.w, A2.x),
                     // q = (A2.y, A2.z, A2.w), e2.q = A3.x, bin offsets = A3.y
                     const float px = ry * A1.y - rz * A1.x;        // p = g x e2, sift.c:278
@@ -1625,7 +1611,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                            !(xb < -1.1920928955078125e-06f || yb < -1.1920928955078125e-06f ||
                              zb < -1.1920928955078125e-06f || kk < 0);            // sift.c:1277-1279
                 };
-                const int pairm = svm[vs] & svm[vs2];
+                const int pairm = c_vmask[vs] & c_vmask[vs2];
                 // cos^2 of the angle to the nearest vertex > 1 - 2e-6  (|vertex|^2 = 1 + g^2)
                 bool slow = __popc(pairm) != 2 || best * best > m2 * (3.6180339887f * (1.0f - 2e-6f));
                 if (!slow) {
@@ -1642,7 +1628,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                     }
                 }
                 if (slow) {
-                    const int five = svf[vs];
+                    const int five = c_vf5[vs];
 #pragma unroll 1
                     for (int k = 0; k < 5; k++) {
                         const int f = (five >> (5 * k)) & 31;
@@ -1678,8 +1664,11 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                     for (int c = 0; c < 8; c++)
                         valid |= ((ix + ((c >> 2) & 1) < 4) && (iy + ((c >> 1) & 1) < 4) &&
                                   (iz + (c & 1) < 4)) ? (1 << c) : 0;
-                    meta0[slot] = (ix + 4 * iy + 16 * iz) | (valid << 6);
-                    meta1[slot] = fidx;
+                    meta0[slot] = valid << 6;
+                    const int cell4 = 4 * (ix + 4 * iy + 16 * iz);
+#pragma unroll
+                    for (int j = 0; j < 3; j++)
+                        ab[j][slot] = 4 * ((fidx >> (10 * j)) & 1023) + cell4;
                 }
             }
         }
@@ -1697,7 +1686,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
         if (!(ablate & 1)) {
             const int hb = half * RODD;
             int4 ma4 = *reinterpret_cast<const int4 *>(&meta0[hb]);
-            int4 mb4 = *reinterpret_cast<const int4 *>(&meta1[hb]);
+            int4 mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb]);
             float4 mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb]);
             float4 bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb]);
 #pragma unroll
@@ -1706,21 +1695,21 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                 const float mv[4] = { mw4.x, mw4.y, mw4.z, mw4.w }, bv[4] = { bw4.x, bw4.y, bw4.z, bw4.w };
                 if (c < 7) {
                     ma4 = *reinterpret_cast<const int4 *>(&meta0[hb + 4 * c + 4]);
-                    mb4 = *reinterpret_cast<const int4 *>(&meta1[hb + 4 * c + 4]);
+                    mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb + 4 * c + 4]);
                     mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb + 4 * c + 4]);
                     bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb + 4 * c + 4]);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const bool on = (ma[u] & on_bit) != 0;                         // sift.c:1349-1352
-                    const int addr = (ma[u] & 63) + coff + ((mb[u] >> (10 * pj)) & 1023);
+                    float *bin = reinterpret_cast<float *>(reinterpret_cast<char *>(hist) + (mb[u] + coff4));
                     const float val = mv[u] * bv[u];                               // sift.c:1371-1373
                     if (half == 0 && on)
-                        hist[addr] = hist[addr] + val;
+                        *bin = *bin + val;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     if (half == 1 && on)
-                        hist[addr] = hist[addr] + val;
+                        *bin = *bin + val;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -1753,33 +1742,47 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                 queue[(qtail + (uint32_t)__popcll(m & lt_mask)) & (DQ - 1)] = pk;
             qtail += (uint32_t)__popcll(m);
             __syncthreads();
-            if (!pend && qtail - qhead >= 64) {
-                prefetch(qhead, 64);
-                pend = true;
-            }
-            if (pend && qtail - qhead >= 128) {
-                float cv[6];
+            // A full batch leaves the queue as soon as its samples are requested (its packed
+            // coordinates travel in ppk), one batch ahead of its binning and commit
+            if (qtail - qhead >= 64) {
+                if (pend) {
+                    float cv[6];
 #pragma unroll
-                for (int k = 0; k < 6; k++)
-                    cv[k] = pv[k];
-                const int cpk = ppk;
-                prefetch(qhead + 64, 64);          // next batch's loads fly during this one
-                batch(64, cv, cpk);
-                qhead += 64;
+                    for (int k = 0; k < 6; k++)
+                        cv[k] = pv[k];
+                    const int cpk = ppk;
+                    prefetch(qhead, 64);           // next batch's loads fly during this one
+                    qhead += 64;
+                    batch(64, cv, cpk);
+                } else {
+                    prefetch(qhead, 64);
+                    qhead += 64;
+                    pend = true;
+                }
             }
         }
     }
-    while (qtail != qhead) {
-        const int cnt = min(64u, qtail - qhead);
-        if (!pend)
-            prefetch(qhead, cnt);
-        pend = false;
-        float cv[6];
+    {
+        int have = pend ? 64 : 0, rest = (int)(qtail - qhead);
+        while (have || rest) {
+            if (!have) {
+                prefetch(qhead, rest);
+                have = rest;
+                rest = 0;
+            }
+            float cv[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++)
-            cv[k] = pv[k];
-        batch(cnt, cv, ppk);
-        qhead += cnt;
+            for (int k = 0; k < 6; k++)
+                cv[k] = pv[k];
+            const int cpk = ppk, cnt = have;
+            have = 0;
+            if (rest) {
+                prefetch(qhead, rest);
+                have = rest;
+                rest = 0;
+            }
+            batch(cnt, cv, cpk);
+        }
     }
     __syncthreads();
     // normalize_desc -> clamp -> normalize_desc (sift.c:1402-1429, 1514-1526).  The double
@@ -2397,6 +2400,19 @@ int sift3d_hip_set_mesh(const float *faces)
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_face_idx), idx, sizeof(idx)));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_verts), verts, sizeof(verts)));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_vert_faces), vfaces, sizeof(vfaces)));
+    {
+        int vf5[12], vmask[12];
+        for (int v = 0; v < 12; v++) {
+            vf5[v] = 0;
+            vmask[v] = 0;
+            for (int k = 0; k < 5; k++) {
+                vf5[v] |= vfaces[v * 5 + k] << (5 * k);
+                vmask[v] |= 1 << vfaces[v * 5 + k];
+            }
+        }
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_vf5), vf5, sizeof(vf5)));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_vmask), vmask, sizeof(vmask)));
+    }
     return SIFT3D_SUCCESS;
 }
 
