@@ -1456,7 +1456,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     // voxels contiguously
     __shared__ __attribute__((aligned(16))) float mw[8][RROW]; // mag * trilinear weight of the eight cells
     __shared__ __attribute__((aligned(16))) float bw[3][RROW]; // barycentric weights
-    __shared__ __attribute__((aligned(16))) int meta0[RROW];   // validity of the eight cell corners, bit 6 + corner
     __shared__ __attribute__((aligned(16))) int ab[3][RROW];   // byte address of bin (base cell, face vertex j) in hist
     __shared__ int queue[DQ];     // xx | yy<<10 | zz<<20, window-relative, in scan order
     const uint32_t ki = blockIdx.x;
@@ -1481,8 +1480,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     bounds_f(K.cx, rad, L.ux, L.nx, B.xs, B.xe);
     bounds_f(K.cy, rad, L.uy, L.ny, B.ys, B.ye);
     bounds_f(K.cz, rad, L.uz, L.nz_glob, B.zs, B.ze);
-    const int bx = B.xe - B.xs + 1, by = B.ye - B.ys + 1;
-    const int npl = bx > 0 && by > 0 ? bx * by : 0;
     // phase B roles: lanes 0..23 commit the first voxel of a pair, lanes 32..55 the second;
     // each committer lane is one (trilinear cell corner, face vertex) pair
     const int half = lane >> 5, l5 = lane & 31;
@@ -1491,7 +1488,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const int slot = (lane & 1) * RODD + (lane >> 1);  // where phase A puts this lane's voxel
     const int pdx = (pc >> 2) & 1, pdy = (pc >> 1) & 1, pdz = pc & 1;
     const int coff4 = 4 * (pdx + 4 * pdy + 16 * pdz);  // byte offset of this lane's cell corner
-    const int on_bit = committer ? 64 << pc : 0;       // its validity bit in meta0
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     __syncthreads();
 
@@ -1535,7 +1531,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         }
     };
     auto batch = [&](int cnt, const float *cv, int pk) {
-        bool ok = false;
+        float mwv[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
         if (ablate & 2) return;
         if (lane < cnt) {
             const int x = B.xs + (pk & 1023), y = B.ys + ((pk >> 10) & 1023), z = B.zs + (pk >> 20);
@@ -1641,30 +1637,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     }
                 }
                 if (face >= 0) {
-                    ok = true;
                     const float mag = sqrtf(m2);                   // sift.c:1331
                     const float fx = vbx - floorf(vbx);            // sift.c:1318-1320
                     const float fy = vby - floorf(vby);
                     const float fz = vbz - floorf(vbz);
-                    const float ax[2] = { 1.0f - fx, fx }, ay[2] = { 1.0f - fy, fy },
-                                az[2] = { 1.0f - fz, fz };
+                    // A corner beyond the last cell is skipped by the reference (sift.c:1349-1352);
+                    // here its weight is forced to 0 and phase B skips zero weights -- adding
+                    // mag * 0 * bary = +-0 would not change a (non-negative) bin either.
+                    const int ix = (int)vbx, iy = (int)vby, iz = (int)vbz;
+                    const float ax[2] = { 1.0f - fx, ix < 3 ? fx : 0.0f },
+                                ay[2] = { 1.0f - fy, iy < 3 ? fy : 0.0f },
+                                az[2] = { 1.0f - fz, iz < 3 ? fz : 0.0f };
 #pragma unroll
                     for (int c = 0; c < 8; c++) {
                         // weight = wx * wy * wz (sift.c:1361-1363); value = mag * weight * bary
                         const float wt = ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1];
-                        mw[c][slot] = mag * wt;
+                        mwv[c] = mag * wt;
                     }
                     bw[0][slot] = b0; bw[1][slot] = b1; bw[2][slot] = b2;
-                    // commit record: base bin of cell (ix,iy,iz), validity of the 8 trilinear
-                    // corners (sift.c:1349-1352), and the three vertex bins -- addressed through
-                    // the UNSWAPPED idx[] of the face (quirk Q1)
-                    const int ix = (int)vbx, iy = (int)vby, iz = (int)vbz;
-                    int valid = 0;
-#pragma unroll
-                    for (int c = 0; c < 8; c++)
-                        valid |= ((ix + ((c >> 2) & 1) < 4) && (iy + ((c >> 1) & 1) < 4) &&
-                                  (iz + (c & 1) < 4)) ? (1 << c) : 0;
-                    meta0[slot] = valid << 6;
+                    // byte addresses of the bins (base cell, face vertex j) -- the vertices
+                    // addressed through the UNSWAPPED idx[] of the face (quirk Q1)
                     const int cell4 = 4 * (ix + 4 * iy + 16 * iz);
 #pragma unroll
                     for (int j = 0; j < 3; j++)
@@ -1672,8 +1664,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 }
             }
         }
-        if (!ok)
-            meta0[slot] = 0;           // no valid corner -> nothing is committed for this voxel
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            mw[c][slot] = mwv[c];      // all zero: nothing is committed for this voxel
         __syncthreads();
         // Ordered commit, two voxels per iteration (2i by lanes 0..23, 2i+1 by lanes 32..55).
         // 24 lanes per voxel (8 cells x 3 face vertices) each own one distinct histogram bin,
@@ -1685,23 +1678,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         // loads, one chunk ahead of the dependent RMW chain.
         if (!(ablate & 1)) {
             const int hb = half * RODD;
-            int4 ma4 = *reinterpret_cast<const int4 *>(&meta0[hb]);
             int4 mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb]);
             float4 mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb]);
             float4 bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb]);
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                const int ma[4] = { ma4.x, ma4.y, ma4.z, ma4.w }, mb[4] = { mb4.x, mb4.y, mb4.z, mb4.w };
+                const int mb[4] = { mb4.x, mb4.y, mb4.z, mb4.w };
                 const float mv[4] = { mw4.x, mw4.y, mw4.z, mw4.w }, bv[4] = { bw4.x, bw4.y, bw4.z, bw4.w };
                 if (c < 7) {
-                    ma4 = *reinterpret_cast<const int4 *>(&meta0[hb + 4 * c + 4]);
                     mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb + 4 * c + 4]);
                     mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb + 4 * c + 4]);
                     bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb + 4 * c + 4]);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const bool on = (ma[u] & on_bit) != 0;                         // sift.c:1349-1352
+                    const bool on = committer && mv[u] != 0.0f;                    // sift.c:1349-1352
                     float *bin = reinterpret_cast<float *>(reinterpret_cast<char *>(hist) + (mb[u] + coff4));
                     const float val = mv[u] * bv[u];                               // sift.c:1371-1373
                     if (half == 0 && on)
@@ -1718,21 +1709,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         __syncthreads();
     };
 
-    for (int z = B.zs; z <= B.ze; z++) {
-        // (yy, xx) of this lane's voxel in the plane, advanced by 64 per chunk without a division
-        int yy = bx > 0 ? lane / bx : 0, xx = bx > 0 ? lane - yy * bx : 0;
-        for (int c0 = 0; c0 < npl; c0 += 64) {
+    // The reference scans the whole bounding box of the sphere (sift.c:96-108).  Every voxel
+    // that passes the window test lies in the sphere AND in the rotated 4x4x4 cube, so each
+    // plane only needs the voxels of a (conservative: +1 voxel, +0.1 %) rectangle around the
+    // plane's disc, clipped to the cube's extent along the image axes; the exact per-voxel
+    // test and the scan order are unchanged.
+    const float cube_x = half_w * (fabsf(R[0]) + fabsf(R[1]) + fabsf(R[2])) * 1.001f;
+    const float cube_y = half_w * (fabsf(R[3]) + fabsf(R[4]) + fabsf(R[5])) * 1.001f;
+    const float cube_z = half_w * (fabsf(R[6]) + fabsf(R[7]) + fabsf(R[8])) * 1.001f;
+    const int zs = max(B.zs, (int)floorf(K.cz - cube_z / L.uz - 1.0f));
+    const int ze = min(B.ze, (int)ceilf(K.cz + cube_z / L.uz + 1.0f));
+    for (int z = zs; z <= ze; z++) {
+        const float dzp = ((float)z - K.cz) * L.uz;
+        const float rz = sqrtf(fmaxf(rad2 - dzp * dzp, 0.0f)) * 1.001f;
+        const float xr = fminf(rz, cube_x) / L.ux + 1.0f, yr = fminf(rz, cube_y) / L.uy + 1.0f;
+        const int pxs = max(B.xs, (int)floorf(K.cx - xr)), pxe = min(B.xe, (int)ceilf(K.cx + xr));
+        const int pys = max(B.ys, (int)floorf(K.cy - yr)), pye = min(B.ye, (int)ceilf(K.cy + yr));
+        const int pbx = pxe - pxs + 1, pby = pye - pys + 1;
+        const int ppl = pbx > 0 && pby > 0 ? pbx * pby : 0;
+        const int ox = pxs - B.xs, oy = pys - B.ys;
+        // (yy, xx) of this lane's voxel in the rectangle, advanced by 64 per chunk without a division
+        int yy = pbx > 0 ? lane / pbx : 0, xx = pbx > 0 ? lane - yy * pbx : 0;
+        for (int c0 = 0; c0 < ppl; c0 += 64) {
             const int i = c0 + lane;
             bool in = false;
             int pk = 0;
-            if (i < npl) {
+            if (i < ppl) {
                 float sq, vbx, vby, vbz;
-                in = window(B.xs + xx, B.ys + yy, z, sq, vbx, vby, vbz);
-                pk = xx | (yy << 10) | ((z - B.zs) << 20);
+                in = window(pxs + xx, pys + yy, z, sq, vbx, vby, vbz);
+                pk = (ox + xx) | ((oy + yy) << 10) | ((z - B.zs) << 20);
             }
             xx += 64;
-            while (xx >= bx) {
-                xx -= bx;
+            while (xx >= pbx) {
+                xx -= pbx;
                 yy++;
             }
             const unsigned long long m = __ballot(in);
