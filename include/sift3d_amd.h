@@ -100,6 +100,8 @@ SIFT3D_AMD_API void *sift3d_hip_malloc(size_t bytes);
 SIFT3D_AMD_API void sift3d_hip_free(void *d_ptr);
 SIFT3D_AMD_API void *sift3d_hip_host_alloc(size_t bytes); /* pinned */
 SIFT3D_AMD_API void sift3d_hip_host_free(void *h_ptr);
+/* device-side address of a sift3d_hip_host_alloc block (kernels may write results into it) */
+SIFT3D_AMD_API void *sift3d_hip_host_device_ptr(void *h_ptr);
 SIFT3D_AMD_API int sift3d_hip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 SIFT3D_AMD_API int sift3d_hip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 SIFT3D_AMD_API int sift3d_hip_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);

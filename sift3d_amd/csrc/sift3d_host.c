@@ -122,7 +122,6 @@ struct _sift3d_detector {
     void *d_work;
     size_t work_bytes;
     sift3d_hip_kp *d_kp, *h_kp;
-    float *d_hist;
     uint32_t kp_cap;
     int have_pyramid;
     int ncand;
@@ -886,7 +885,6 @@ void sift3d_free_detector(sift3d_detector *d)
     sift3d_hip_free(d->d_R);
     sift3d_hip_free(d->d_keep);
     sift3d_hip_free(d->d_kp);
-    sift3d_hip_free(d->d_hist);
     sift3d_hip_host_free(d->h_cand);
     sift3d_hip_host_free(d->h_R);
     sift3d_hip_host_free(d->h_keep);
@@ -1279,13 +1277,11 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
     if ((uint32_t)num > d->kp_cap) {
         const uint32_t cap = (uint32_t)num + (uint32_t)num / 4 + 256;
         sift3d_hip_free(d->d_kp);
-        sift3d_hip_free(d->d_hist);
         sift3d_hip_host_free(d->h_kp);
         d->kp_cap = 0;
         d->d_kp = (sift3d_hip_kp *)sift3d_hip_malloc(sizeof(sift3d_hip_kp) * (size_t)cap);
-        d->d_hist = (float *)sift3d_hip_malloc(sizeof(float) * DESC_NUMEL * (size_t)cap);
         d->h_kp = (sift3d_hip_kp *)sift3d_hip_host_alloc(sizeof(sift3d_hip_kp) * (size_t)cap);
-        if (!d->d_kp || !d->d_hist || !d->h_kp)
+        if (!d->d_kp || !d->h_kp)
             return SIFT3D_FAILURE;
         d->kp_cap = cap;
     }
@@ -1303,8 +1299,7 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
     desc->nx = d->odims[0][0];
     desc->ny = d->odims[0][1];
     desc->nz = d->odims[0][2];
-    /* the store's histogram array is page-locked so that histograms land in it straight from
-     * HBM, chunk by chunk on a second stream while the next chunk's kernel runs */
+    /* the store's histogram array is page-locked and device-visible */
     if (!desc->pinned || (size_t)num > desc->cap) {
         const size_t cap = (size_t)num + (size_t)num / 8 + 64;
         desc_store_release(desc);
@@ -1322,21 +1317,15 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
     sift3d_hip_event_record(d->ev[6], d->stream);
     if (sift3d_hip_memcpy_h2d(d->d_kp, d->h_kp, sizeof(sift3d_hip_kp) * (size_t)num, d->stream))
         return SIFT3D_FAILURE;
+    /* The kernel stores each histogram straight into the store's page-locked array (mapped
+     * into the device's address space): the 3 KB per keypoint trickle over PCIe while the other
+     * keypoints are still being computed, so there is no device staging buffer and no D2H
+     * copy after the kernel.  (A chunked kernel/copy pipeline measured slower: every chunk
+     * pays the kernel's long tail.) */
     {
-        const int nch = 1; /* chunked kernel/copy overlap measured slower (tail effects): one launch */
-        int c;
-        for (c = 0; c < nch; c++) {
-            const size_t i0 = (size_t)num * c / nch, i1 = (size_t)num * (c + 1) / nch;
-            if (i1 == i0)
-                continue;
-            if (sift3d_hip_describe(d->d_levels, d->d_kp + i0, (uint32_t)(i1 - i0),
-                                    d->d_hist + DESC_NUMEL * i0, d->stream) ||
-                sift3d_hip_event_record(d->ev_chunk[c], d->stream) ||
-                sift3d_hip_stream_wait_event(d->copy_stream, d->ev_chunk[c]) ||
-                sift3d_hip_memcpy_d2h(desc->hist + DESC_NUMEL * i0, d->d_hist + DESC_NUMEL * i0,
-                                      sizeof(float) * DESC_NUMEL * (i1 - i0), d->copy_stream))
-                return SIFT3D_FAILURE;
-        }
+        float *dev_view = (float *)sift3d_hip_host_device_ptr(desc->hist);
+        if (!dev_view || sift3d_hip_describe(d->d_levels, d->d_kp, (uint32_t)num, dev_view, d->stream))
+            return SIFT3D_FAILURE;
     }
     sift3d_hip_event_record(d->ev[7], d->stream);
     for (i = 0; i < num; i++) {
@@ -1347,7 +1336,7 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
         desc->xyzsd[4 * (size_t)i + 2] = k->zd * f;
         desc->xyzsd[4 * (size_t)i + 3] = k->sd;
     }
-    if (sift3d_hip_stream_sync(d->stream) || sift3d_hip_stream_sync(d->copy_stream))
+    if (sift3d_hip_stream_sync(d->stream))
         return SIFT3D_FAILURE;
     d->t[5] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[6], d->ev[7]);
     d->t[8] = now_s() - t_start;

@@ -95,6 +95,17 @@ void *sift3d_hip_host_alloc(size_t bytes)
     return p;
 }
 
+void *sift3d_hip_host_device_ptr(void *host)
+{
+    void *dev = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&dev, host, 0);
+    if (e != hipSuccess) {
+        fail("hipHostGetDevicePointer", e, __FILE__, __LINE__);
+        return nullptr;
+    }
+    return dev;
+}
+
 void sift3d_hip_host_free(void *p)
 {
     if (p)
