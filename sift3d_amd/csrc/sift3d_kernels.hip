@@ -1274,8 +1274,9 @@ __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restric
                                                double corner_thresh, float *__restrict__ Rout,
                                                int32_t *__restrict__ keep)
 {
-    __shared__ double td[6][64];
-    __shared__ float tf[3][64];
+    // rows padded by 16 bytes: the accumulator lanes' 16-byte reads fall on different banks
+    __shared__ __attribute__((aligned(16))) double td[6][66];
+    __shared__ __attribute__((aligned(16))) float tf[3][68];
     const uint32_t ci = blockIdx.x;
     if (ci >= n)
         return;
@@ -1296,11 +1297,10 @@ __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restric
     bounds_d(cx, rad, L.ux, L.nx, B.xs, B.xe);
     bounds_d(cy, rad, L.uy, L.ny, B.ys, B.ye);
     bounds_d(cz, rad, L.uz, L.nz_glob, B.zs, B.ze);
-    const int bx = B.xe - B.xs + 1, by = B.ye - B.ys + 1;
-    const int npl = bx > 0 && by > 0 ? bx * by : 0;
-
     double dacc = 0.0; // lanes 0..5: A00 A01 A02 A11 A12 A22
     float facc = 0.0f; // lanes 6..8: vd_win x y z
+    const double *tdp = td[lane < 6 ? lane : 0];
+    const float *tfp = tf[lane >= 6 && lane < 9 ? lane - 6 : 0];
     __shared__ int queue[256];   // in-sphere voxels, window relative, in scan order
     uint32_t qhead = 0, qtail = 0;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -1331,34 +1331,47 @@ __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restric
         tf[1][lane] = in ? gy * w : 0.0f;
         tf[2][lane] = in ? gz * w : 0.0f;
         __syncthreads();
-        if (lane < 6) {
+        // Every lane runs both serial sums (the double and the float chain interleave and hide
+        // each other's latency); only lanes 0..5 / 6..8 hold meaningful rows.
 #pragma unroll
-            for (int j = 0; j < 64; j++)
-                dacc += td[lane][j];
-        } else if (lane < 9) {
-#pragma unroll
-            for (int j = 0; j < 64; j++)
-                facc += tf[lane - 6][j];
+        for (int j = 0; j < 64; j += 4) {
+            const double2 d01 = *reinterpret_cast<const double2 *>(&tdp[j]);
+            const double2 d23 = *reinterpret_cast<const double2 *>(&tdp[j + 2]);
+            const float4 f4 = *reinterpret_cast<const float4 *>(&tfp[j]);
+            dacc += d01.x; facc += f4.x;
+            dacc += d01.y; facc += f4.y;
+            dacc += d23.x; facc += f4.z;
+            dacc += d23.y; facc += f4.w;
         }
         __syncthreads();
     };
 
+    // Only the (conservative: +1 voxel, +0.1 %) bounding rectangle of each plane's disc is
+    // scanned; the exact per-voxel test (sift.c:106) and the scan order are unchanged.
+    const float rad2f = (float)rad2;
     for (int z = B.zs; z <= B.ze; z++) {
         const float dz = ((float)z - cz) * L.uz;
-        int yy = bx > 0 ? lane / bx : 0, xx = bx > 0 ? lane - yy * bx : 0;
-        for (int c0 = 0; c0 < npl; c0 += 64) {
+        const float rz = sqrtf(fmaxf(rad2f - dz * dz, 0.0f)) * 1.001f;
+        const float xr = rz / L.ux + 1.0f, yr = rz / L.uy + 1.0f;
+        const int pxs = max(B.xs, (int)floorf(cx - xr)), pxe = min(B.xe, (int)ceilf(cx + xr));
+        const int pys = max(B.ys, (int)floorf(cy - yr)), pye = min(B.ye, (int)ceilf(cy + yr));
+        const int pbx = pxe - pxs + 1, pby = pye - pys + 1;
+        const int ppl = pbx > 0 && pby > 0 ? pbx * pby : 0;
+        const int ox = pxs - B.xs, oy = pys - B.ys;
+        int yy = pbx > 0 ? lane / pbx : 0, xx = pbx > 0 ? lane - yy * pbx : 0;
+        for (int c0 = 0; c0 < ppl; c0 += 64) {
             bool in = false;
             int pk = 0;
-            if (c0 + lane < npl) {
-                const float dx = ((float)(B.xs + xx) - cx) * L.ux;
-                const float dy = ((float)(B.ys + yy) - cy) * L.uy;
+            if (c0 + lane < ppl) {
+                const float dx = ((float)(pxs + xx) - cx) * L.ux;
+                const float dy = ((float)(pys + yy) - cy) * L.uy;
                 const float sq = dx * dx + dy * dy + dz * dz;
                 in = !((double)sq > rad2);                        // sift.c:106 (double)
-                pk = xx | (yy << 10) | ((z - B.zs) << 20);
+                pk = (ox + xx) | ((oy + yy) << 10) | ((z - B.zs) << 20);
             }
             xx += 64;
-            while (xx >= bx) {
-                xx -= bx;
+            while (xx >= pbx) {
+                xx -= pbx;
                 yy++;
             }
             const unsigned long long m = __ballot(in);
