@@ -1482,6 +1482,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     __shared__ __attribute__((aligned(16))) float bw[3][RROW]; // barycentric weights
     __shared__ __attribute__((aligned(16))) int ab[3][RROW];   // byte address of bin (base cell, face vertex j) in hist
     __shared__ int queue[DQ];     // xx | yy<<10 | zz<<20, window-relative, in scan order
+    __shared__ int svm[12], svf[12]; // faces around each vertex: 20-bit mask / five 5-bit ids
     const uint32_t ki = blockIdx.x;
     if (ki >= n)
         return;
@@ -1490,6 +1491,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const sift3d_hip_level L = levels[K.level];
     for (int i = lane; i < HIST_LDS; i += 64)
         hist[i] = 0.0f;
+    if (lane < 12) {
+        svm[lane] = c_vmask[lane];
+        svf[lane] = c_vf5[lane];
+    }
 
     const float sigma = (float)(K.sd * 7.071067812);                  // sift.c:1453
     const float rad = (float)(2.0 * (double)sigma);                   // sift.c:1454
@@ -1541,7 +1546,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     // One batch: the next `cnt` (<= 64) queued voxels, in scan order.
     // The six gradient samples of a batch are fetched one batch ahead (registers pv/ppk), so
     // their HBM/L2 latency overlaps the previous batch's binning and commit.
-    float pv[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    float pv[7] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     int ppk = 0;
     auto prefetch = [&](uint32_t start, int cnt) {
         if (lane < cnt) {
@@ -1552,6 +1557,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const float *p = L.data + (size_t)x + ys * y + zs * zl;
             pv[0] = p[1]; pv[1] = *(p - 1); pv[2] = p[ys]; pv[3] = *(p - ys);
             pv[4] = p[zs]; pv[5] = *(p - zs);
+            // the Gaussian weight only needs the coordinates: its table look-up (constant
+            // memory) also flies one batch ahead
+            const float dx = ((float)x - K.cx) * L.ux;                 // sift.c:102-104
+            const float dy = ((float)y - K.cy) * L.uy;
+            const float dz = ((float)(B.zs + (ppk >> 20)) - K.cz) * L.uz;
+            pv[6] = s3d_expf(-0.5f * (dx * dx + dy * dy + dz * dz) / sig2); // sift.c:1498
         }
     };
     auto batch = [&](int cnt, const float *cv, int pk) {
@@ -1566,7 +1577,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             gx *= 1.0f / L.ux;
             gy *= 1.0f / L.uy;
             gz *= 1.0f / L.uz;
-            const float w = s3d_expf(-0.5f * sq / sig2);           // sift.c:1498
+            const float w = cv[6];                                 // sift.c:1498, see prefetch
             gx = gx * w; gy = gy * w; gz = gz * w;
             const float rx = R[0] * gx + R[3] * gy + R[6] * gz;    // sift.c:1502
             const float ry = R[1] * gx + R[4] * gy + R[7] * gz;
@@ -1631,7 +1642,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                            !(xb < -1.1920928955078125e-06f || yb < -1.1920928955078125e-06f ||
                              zb < -1.1920928955078125e-06f || kk < 0);            // sift.c:1277-1279
                 };
-                const int pairm = c_vmask[vs] & c_vmask[vs2];
+                const int pairm = svm[vs] & svm[vs2];
                 // cos^2 of the angle to the nearest vertex > 1 - 2e-6  (|vertex|^2 = 1 + g^2)
                 bool slow = __popc(pairm) != 2 || best * best > m2 * (3.6180339887f * (1.0f - 2e-6f));
                 if (!slow) {
@@ -1648,7 +1659,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                     }
                 }
                 if (slow) {
-                    const int five = c_vf5[vs];
+                    const int five = svf[vs];
 #pragma unroll 1
                     for (int k = 0; k < 5; k++) {
                         const int f = (five >> (5 * k)) & 31;
@@ -1779,9 +1790,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             // coordinates travel in ppk), one batch ahead of its binning and commit
             if (qtail - qhead >= 64) {
                 if (pend) {
-                    float cv[6];
+                    float cv[7];
 #pragma unroll
-                    for (int k = 0; k < 6; k++)
+                    for (int k = 0; k < 7; k++)
                         cv[k] = pv[k];
                     const int cpk = ppk;
                     prefetch(qhead, 64);           // next batch's loads fly during this one
@@ -1803,9 +1814,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                 have = rest;
                 rest = 0;
             }
-            float cv[6];
+            float cv[7];
 #pragma unroll
-            for (int k = 0; k < 6; k++)
+            for (int k = 0; k < 7; k++)
                 cv[k] = pv[k];
             const int cpk = ppk, cnt = have;
             have = 0;
