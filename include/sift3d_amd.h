@@ -177,6 +177,14 @@ SIFT3D_AMD_API int
 sift3d_hip_subtract_absmax(const float *d_a, const float *d_b, float *d_dst, size_t n,
                            float *d_absmax, void *stream);
 
+/* build_dog (sift.c:713-732) for one octave in one pass: d_d[k] = d_g[k] - d_g[k+1] for
+ * k < n_gauss-1 and d_absmax[k] = max(d_absmax[k], max|d_d[k]|).  Every Gaussian level is read
+ * once.  Returns 1 (nothing done) when n_gauss > SIFT3D_HIP_MAX_DOG_STACK or a pointer is not
+ * 16-byte aligned: the caller then uses sift3d_hip_subtract_absmax per level pair. */
+#define SIFT3D_HIP_MAX_DOG_STACK 8
+SIFT3D_AMD_API int sift3d_hip_dog_stack(const float *const *d_g, float *const *d_d, int n_gauss,
+                                        size_t n, float *d_absmax, void *stream);
+
 /* im_downsample_2x (imutil.c:591-617): dst(x,y,z) = src(2x,2y,2z) for the mx*my*mz
  * output box; src rows are nx long, planes nx*ny. */
 SIFT3D_AMD_API int

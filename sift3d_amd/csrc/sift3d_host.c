@@ -1089,6 +1089,14 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     /* build_dog (sift.c:713-732) fused with the dogmax scan (sift.c:821-826) */
     for (o = 0; o < d->num_octaves; o++) {
         const size_t n = (size_t)d->odims[o][0] * d->odims[o][1] * d->odims[o][2];
+        /* one pass over the octave's Gaussian levels when the stack kernel covers it */
+        const int rc = sift3d_hip_dog_stack((const float *const *)(d->d_g + o * d->ngl),
+                                            d->d_d + o * d->ndl, d->ngl, n,
+                                            d->d_scalars + 8 + o * d->ndl, d->stream);
+        if (rc == SIFT3D_SUCCESS)
+            continue;
+        if (rc != 1)
+            return SIFT3D_FAILURE;
         for (s = 0; s < d->ndl; s++)
             if (sift3d_hip_subtract_absmax(d->d_g[o * d->ngl + s], d->d_g[o * d->ngl + s + 1],
                                            d->d_d[o * d->ndl + s], n,

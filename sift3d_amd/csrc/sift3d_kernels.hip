@@ -421,7 +421,10 @@ __global__ __launch_bounds__(256) void k_fir_x_u1(FirParams P, FirTaps T, EdgeTa
     __shared__ __attribute__((aligned(16))) float lds[4][2][L];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nrows = P.ny * (P.z_hi - P.z_lo);
-    const int row0 = (blockIdx.y * 4 + wave) * XROWS;
+    // Blocks walk the volume from its LAST rows to its first: the producer of `src` (the
+    // previous blur's z sweep) finished there, so those planes are still in the 256 MB
+    // Infinity Cache; the consumer of `dst` starts at plane 0, where this kernel ends.
+    const int row0 = ((gridDim.y - 1 - blockIdx.y) * 4 + wave) * XROWS;
     if (row0 >= nrows)
         return;
     const int nr = min(XROWS, nrows - row0);
@@ -1065,6 +1068,58 @@ __global__ __launch_bounds__(256) void k_sub_absmax(const float *__restrict__ a,
 // ---------------------------------------------------------------------------------------
 // im_downsample_2x  (imutil.c:591-617)
 // ---------------------------------------------------------------------------------------
+// All DoG levels of one octave in one pass: NL Gaussian levels are read once (4*NL B/voxel) and
+// NL-1 differences written, instead of 12 B/voxel per level pair.  Same arithmetic and the same
+// order-free max as k_sub_absmax.
+struct DogStack {
+    const float *g[SIFT3D_HIP_MAX_DOG_STACK];
+    float *d[SIFT3D_HIP_MAX_DOG_STACK - 1];
+    unsigned *out; // NL-1 consecutive maxima (float bits)
+};
+
+template <int NL>
+__global__ __launch_bounds__(256) void k_dog_stack(DogStack S, size_t n)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthr = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = n >> 2;
+    float m[NL - 1];
+#pragma unroll
+    for (int k = 0; k < NL - 1; k++)
+        m[k] = 0.0f;
+    for (size_t i = tid; i < n4; i += nthr) {
+        float4 v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++)
+            v[k] = ld4(S.g[k] + 4 * i);
+#pragma unroll
+        for (int k = 0; k < NL - 1; k++) {
+            float4 r;
+            r.x = v[k].x - v[k + 1].x; r.y = v[k].y - v[k + 1].y;
+            r.z = v[k].z - v[k + 1].z; r.w = v[k].w - v[k + 1].w;
+            st4(S.d[k] + 4 * i, r);
+            m[k] = fmaxf(m[k], fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
+        }
+    }
+    for (size_t j = 4 * n4 + tid; j < n; j += nthr) {
+        float prev = S.g[0][j];
+#pragma unroll
+        for (int k = 0; k < NL - 1; k++) {
+            const float cur = S.g[k + 1][j];
+            const float r = prev - cur;
+            S.d[k][j] = r;
+            m[k] = fmaxf(m[k], fabsf(r));
+            prev = cur;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NL - 1; k++) {
+        const float w = wave_max(m[k]);
+        if ((threadIdx.x & 63) == 0 && w > 0.0f)
+            atomicMax(S.out + k, __float_as_uint(w));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_downsample2(const float *__restrict__ src, int nx, int ny,
                                                      float *__restrict__ dst, int mx, int my,
                                                      int mz)
@@ -2068,6 +2123,12 @@ static void launch_fir_yz(const FirParams &P, const FirTaps &T, const EdgeTab &E
         hipLaunchKernelGGL((k_fir_yz_u1<HW, 16>), grid, dim3(16 * 16), 0, st, P, T, Ey, Ez);
 }
 
+template <int NL>
+static void launch_dog_stack(const DogStack &S, size_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_dog_stack<NL>), dim3(grid_for(n, 8)), dim3(256), 0, st, S, n);
+}
+
 static bool is_dyadic(float uf, int *shift)
 {
     int e;
@@ -2278,6 +2339,37 @@ int sift3d_hip_subtract_absmax(const float *d_a, const float *d_b, float *d_dst,
         return SIFT3D_SUCCESS;
     hipLaunchKernelGGL(k_sub_absmax, dim3(grid_for(n, 16)), dim3(256), 0, (hipStream_t)stream, d_a,
                        d_b, d_dst, n, reinterpret_cast<unsigned *>(d_absmax));
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_dog_stack(const float *const *d_g, float *const *d_d, int n_gauss, size_t n,
+                         float *d_absmax, void *stream)
+{
+    if (n_gauss < 2 || n_gauss > SIFT3D_HIP_MAX_DOG_STACK)
+        return 1; // not covered: the caller subtracts level pairs
+    if (!n)
+        return SIFT3D_SUCCESS;
+    DogStack S;
+    memset(&S, 0, sizeof(S));
+    for (int k = 0; k < n_gauss; k++) {
+        S.g[k] = d_g[k];
+        if (((uintptr_t)d_g[k] & 15) || (k < n_gauss - 1 && ((uintptr_t)d_d[k] & 15)))
+            return 1;
+        if (k < n_gauss - 1)
+            S.d[k] = d_d[k];
+    }
+    S.out = reinterpret_cast<unsigned *>(d_absmax);
+    hipStream_t st = (hipStream_t)stream;
+    switch (n_gauss) {
+    case 2: launch_dog_stack<2>(S, n, st); break;
+    case 3: launch_dog_stack<3>(S, n, st); break;
+    case 4: launch_dog_stack<4>(S, n, st); break;
+    case 5: launch_dog_stack<5>(S, n, st); break;
+    case 6: launch_dog_stack<6>(S, n, st); break;
+    case 7: launch_dog_stack<7>(S, n, st); break;
+    default: launch_dog_stack<8>(S, n, st); break;
+    }
     LAUNCH_CHECK();
     return SIFT3D_SUCCESS;
 }

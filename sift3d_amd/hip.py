@@ -74,6 +74,8 @@ def lib():
         "sift3d_hip_fir_yz_u1": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
         "sift3d_hip_subtract_absmax": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp]),
+        "sift3d_hip_dog_stack": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_size_t, vp, vp]),
+        "sift3d_hip_host_device_ptr": (vp, [vp]),
         "sift3d_hip_downsample2": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
         "sift3d_hip_extrema_work_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
         "sift3d_hip_extrema": (C.c_int, [C.POINTER(ExtremaLevel), C.c_int, C.c_int, C.c_int, C.c_int,
@@ -146,6 +148,20 @@ def subtract_absmax(a, b, dst, d_absmax=None):
     _check(lib().sift3d_hip_subtract_absmax(a.data_ptr(), b.data_ptr(), dst.data_ptr(), a.numel(),
                                             d_absmax.data_ptr() if d_absmax is not None else None,
                                             current_stream()), "sift3d_hip_subtract_absmax")
+
+
+def dog_stack(gauss, dogs, d_absmax):
+    """dogs[k] = gauss[k] - gauss[k+1] for one octave in a single pass; d_absmax: float32 tensor
+    of len(gauss)-1 running maxima.  Returns False when the kernel does not cover the case."""
+    n = len(gauss)
+    assert len(dogs) == n - 1 and d_absmax.numel() >= n - 1
+    g = (C.c_void_p * n)(*[t.data_ptr() for t in gauss])
+    d = (C.c_void_p * (n - 1))(*[t.data_ptr() for t in dogs])
+    rc = lib().sift3d_hip_dog_stack(g, d, n, gauss[0].numel(), d_absmax.data_ptr(), current_stream())
+    if rc == 1:
+        return False
+    _check(rc, "sift3d_hip_dog_stack")
+    return True
 
 
 def downsample2(src, dst):

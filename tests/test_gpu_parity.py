@@ -212,6 +212,17 @@ def test_scale_dog_downsample(gpu, oracle_mod):
     hip.subtract_absmax(da, db, out, dm)
     np.testing.assert_array_equal(out.cpu().numpy(), a - b)
     assert dm.item() == np.abs(a - b).max()
+    # the one-pass octave kernel == level pairs, incl. a size that is not a multiple of 4
+    for shape in ((18, 21, 37), (16, 16, 16)):
+        g = [torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).cuda() for _ in range(6)]
+        dd = [torch.empty_like(g[0]) for _ in range(5)]
+        mm = torch.zeros(5, device="cuda")
+        assert hip.dog_stack(g, dd, mm)
+        for k in range(5):
+            want = g[k].cpu().numpy() - g[k + 1].cpu().numpy()
+            np.testing.assert_array_equal(dd[k].cpu().numpy(), want)
+            assert mm[k].item() == np.abs(want).max()
+    assert not hip.dog_stack(g + g, dd + dd + [dd[0]], torch.zeros(11, device="cuda"))  # 12 levels
     ds = torch.empty((9, 10, 18), device="cuda")
     hip.downsample2(da, ds)
     np.testing.assert_array_equal(ds.cpu().numpy(), oracle_mod.downsample(a))
