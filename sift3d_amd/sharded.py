@@ -110,8 +110,8 @@ class HipBackend:
     def empty(self, shape):
         return self.torch.empty(shape, dtype=self.torch.float32, device="cuda")
 
-    def scalar(self):
-        return self.torch.zeros(1, dtype=self.torch.float32, device="cuda")
+    def scalar(self, n=1):
+        return self.torch.zeros(n, dtype=self.torch.float32, device="cuda")
 
     def absmax(self, t, out):
         self.hip.absmax(t, out)
@@ -128,6 +128,10 @@ class HipBackend:
 
     def subtract_absmax(self, a, b, dst, out):
         self.hip.subtract_absmax(a, b, dst, out)
+
+    def dog_stack(self, gauss, dogs, out):
+        """All DoG levels of an octave in one pass; False = not covered (use level pairs)."""
+        return self.hip.dog_stack(gauss, dogs, out)
 
     def downsample2(self, src, dst):
         self.hip.downsample2(src, dst)
@@ -276,7 +280,10 @@ class ShardedSift3D:
         z0, z1 = g.own(0, r) if g.sharded(0) else (0, g.dims[0][2])
         self.in_own = (z0, z1)
         self.raw = be.empty((z1 - z0, g.dims[0][1], g.dims[0][0]))
-        self.dogmax = [[be.scalar() for _ in range(g.ndl)] for _ in range(g.num_octaves)]
+        # per octave one contiguous array of maxima; dogmax[o][s] are 1-element views of it
+        self._dogmax_o = [be.scalar(g.ndl) for _ in range(g.num_octaves)]
+        self.dogmax = [[self._dogmax_o[o][s:s + 1] for s in range(g.ndl)]
+                       for o in range(g.num_octaves)]
         self.inmax = be.scalar()
 
     # ---- communication ------------------------------------------------------------------
@@ -481,17 +488,22 @@ class ShardedSift3D:
                 self._halo(self.G[o][s], WINDOW_HALO if 1 <= s <= g.K else 1)
         # build_dog (sift.c:713-732) + dogmax (sift.c:821-826)
         scal = []
+        stack = getattr(be, "dog_stack", None)
         for o in range(g.num_octaves):
-            for s in range(g.ndl):
-                d, ga, gb = self.D[o][s], self.G[o][s], self.G[o][s + 1]
-                self.dogmax[o][s].zero_()
-                if g.sharded(o):
-                    a, b = d.own()
-                    lo, hi = max(a - 1, 0), min(b + 1, d.t.shape[0])
-                else:
-                    lo, hi = 0, d.t.shape[0]
-                be.subtract_absmax(ga.t[lo:hi], gb.t[lo:hi], d.t[lo:hi], self.dogmax[o][s])
-                scal.append(self.dogmax[o][s])
+            self._dogmax_o[o].zero_()
+            d0 = self.D[o][0]
+            if g.sharded(o):
+                a, b = d0.own()
+                lo, hi = max(a - 1, 0), min(b + 1, d0.t.shape[0])
+            else:
+                lo, hi = 0, d0.t.shape[0]
+            if not (stack and stack([self.G[o][s].t[lo:hi] for s in range(g.ngl)],
+                                    [self.D[o][s].t[lo:hi] for s in range(g.ndl)],
+                                    self._dogmax_o[o])):
+                for s in range(g.ndl):
+                    be.subtract_absmax(self.G[o][s].t[lo:hi], self.G[o][s + 1].t[lo:hi],
+                                       self.D[o][s].t[lo:hi], self.dogmax[o][s])
+            scal.extend(self.dogmax[o])
         self._allreduce_max(scal)
         # detect_extrema (sift.c:735-871) on the owned planes of every octave, then
         # assign_orientations (sift.c:1109-1167) for the local candidates

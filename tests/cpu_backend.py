@@ -35,8 +35,8 @@ class OracleBackend:
     def empty(self, shape):
         return torch.full(tuple(shape), float("nan"), dtype=torch.float32)
 
-    def scalar(self):
-        return torch.zeros(1, dtype=torch.float32)
+    def scalar(self, n=1):
+        return torch.zeros(n, dtype=torch.float32)
 
     def absmax(self, t, out):
         if t.numel():
