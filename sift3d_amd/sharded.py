@@ -185,15 +185,18 @@ class HipBackend:
         n = len(kps)
         if n == 0:
             return np.zeros((0, 768), np.float32)
-        if getattr(self, "_hist", None) is None or self._hist.shape[0] < n:
+        # histograms are stored straight into page-locked host memory (as the C API does)
+        if getattr(self, "_hist_host", None) is None or self._hist_host.shape[0] < n:
             cap = n + n // 8 + 64
-            self._hist = torch.empty((cap, 768), dtype=torch.float32, device="cuda")
             self._hist_host = torch.empty((cap, 768), dtype=torch.float32, pin_memory=True)
+            self._hist_dev = hip.lib().sift3d_hip_host_device_ptr(self._hist_host.data_ptr())
+            if not self._hist_dev:
+                raise RuntimeError("pinned descriptor buffer is not visible to the device: %s"
+                                   % hip.lib().sift3d_hip_last_error().decode())
         dk = torch.from_numpy(np.ascontiguousarray(kps).view(np.uint8)).cuda()
         hip._check(hip.lib().sift3d_hip_describe(table.data_ptr(), dk.data_ptr(), n,
-                                                 self._hist.data_ptr(), hip.current_stream()),
+                                                 self._hist_dev, hip.current_stream()),
                    "sift3d_hip_describe")
-        self._hist_host[:n].copy_(self._hist[:n], non_blocking=True)
         torch.cuda.synchronize()
         return self._hist_host[:n].numpy()
 
