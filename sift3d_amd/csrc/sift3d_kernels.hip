@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(256) void k_downsample2(const float *__restrict__ s
 // ---------------------------------------------------------------------------------------
 // detect_extrema  (sift.c:735-871): mask -> scan -> emit, output in scan order
 // ---------------------------------------------------------------------------------------
-constexpr int EX_WPB = 32; // 64-voxel words per block (8 per wave)
+constexpr int EX_WPB = 128; // 64-voxel words per block (32 per wave)
 
 struct ExLevels {
     sift3d_hip_extrema_level lv[8];
@@ -1155,39 +1155,63 @@ __global__ __launch_bounds__(256) void k_extrema_mask(ExLevels LV, ExGeom E,
                                                       uint32_t *__restrict__ blk_counts)
 {
     __shared__ uint32_t wc[4];
+    constexpr int WPW = EX_WPB / 4; // words per wave
     const int level = blockIdx.y;
     const sift3d_hip_extrema_level L = LV.lv[level];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // thr = (float)(peak_thresh * dogmax), sift.c:829
     const float thr = (float)(E.peak_thresh * (double)(*L.d_absmax));
     const size_t ys = E.nx, zs = (size_t)E.nx * E.ny;
+    const uint32_t wbase = blockIdx.x * EX_WPB + wave * WPW;
     uint32_t cnt = 0;
-    for (int w = 0; w < EX_WPB / 4; w++) {
-        const uint32_t word = blockIdx.x * EX_WPB + wave * (EX_WPB / 4) + w;
-        if (word >= E.nwords)
-            break; // wave-uniform
-        const uint32_t row = word / E.wpr;
-        const int x = (int)(word % E.wpr) * 64 + lane;
-        const int z = (int)(row / E.ny);
-        const int y = (int)(row % E.ny);
-        bool hit = false;
-        if (z >= L.z_lo && z < L.z_hi && y >= 1 && y <= E.ny - 2 && x >= 1 && x <= E.nx - 2) {
-            const size_t p = (size_t)x + ys * y + zs * z;
-            const float v = L.cur[p];
-            if (v > thr || v < -thr) {                               // sift.c:842
-                const float n0 = L.prev[p], n1 = L.cur[p + 1], n2 = L.cur[p - 1],
-                            n3 = L.cur[p + ys], n4 = L.cur[p - ys], n5 = L.cur[p - zs],
-                            n6 = L.cur[p + zs], n7 = L.next[p];
-                hit = (v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6 &&
-                       v > n7) ||
-                      (v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6 &&
-                       v < n7);                                      // sift.c:844-849
+    if (wbase < E.nwords) {
+        // (z, y, word-in-row) of the wave's first word; advanced without divisions afterwards
+        const uint32_t row0 = wbase / E.wpr;
+        int xw = (int)(wbase - row0 * E.wpr);
+        int z = (int)(row0 / E.ny), y = (int)(row0 - (uint32_t)z * E.ny);
+        const uint32_t wend = min(wbase + WPW, E.nwords);
+        for (uint32_t word = wbase; word < wend; word += 4) {
+            // four words per iteration: their centre samples are loaded together
+            float v[4];
+            size_t p[4];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = xw * 64 + lane;
+                ok[k] = word + k < wend && z >= L.z_lo && z < L.z_hi && y >= 1 && y <= E.ny - 2 &&
+                        x >= 1 && x <= E.nx - 2;
+                p[k] = (size_t)x + ys * y + zs * z;
+                v[k] = ok[k] ? L.cur[p[k]] : 0.0f;
+                if (++xw == E.wpr) {
+                    xw = 0;
+                    if (++y == E.ny) {
+                        y = 0;
+                        ++z;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                bool hit = false;
+                if (ok[k] && (v[k] > thr || v[k] < -thr)) {              // sift.c:842
+                    const size_t q = p[k];
+                    const float c = v[k];
+                    const float n0 = L.prev[q], n1 = L.cur[q + 1], n2 = L.cur[q - 1],
+                                n3 = L.cur[q + ys], n4 = L.cur[q - ys], n5 = L.cur[q - zs],
+                                n6 = L.cur[q + zs], n7 = L.next[q];
+                    hit = (c > n0 && c > n1 && c > n2 && c > n3 && c > n4 && c > n5 && c > n6 &&
+                           c > n7) ||
+                          (c < n0 && c < n1 && c < n2 && c < n3 && c < n4 && c < n5 && c < n6 &&
+                           c < n7);                                      // sift.c:844-849
+                }
+                const unsigned long long m = __ballot(hit);
+                if (word + k < wend) {
+                    if (lane == 0)
+                        masks[(size_t)level * E.nwords + word + k] = m;
+                    cnt += (uint32_t)__popcll(m);
+                }
             }
         }
-        const unsigned long long m = __ballot(hit);
-        if (lane == 0)
-            masks[(size_t)level * E.nwords + word] = m;
-        cnt += (uint32_t)__popcll(m);
     }
     if (lane == 0)
         wc[wave] = cnt;
@@ -1196,7 +1220,7 @@ __global__ __launch_bounds__(256) void k_extrema_mask(ExLevels LV, ExGeom E,
         blk_counts[(size_t)level * E.nblk + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
 
-// exclusive scan of the block counts (single workgroup), based at *d_count
+// exclusive scan of the block counts (all levels of the launch), continuing from *d_count
 __global__ __launch_bounds__(1024) void k_extrema_scan(uint32_t *__restrict__ blk, uint32_t n,
                                                        uint32_t *__restrict__ d_count)
 {
