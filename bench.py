@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--size", type=int, default=512, help="edge of the (per-GPU) volume")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-micro", action="store_true", help="skip the per-kernel microbench")
+    ap.add_argument("--sharded", action="store_true",
+                    help="N=1 only: run the Z-slab driver (sift3d_amd.sharded) instead of the C API, "
+                         "to measure the driver's own overhead")
     a = ap.parse_args()
 
     import torch
@@ -158,7 +161,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = a.size
-    if world == 1:
+    if world == 1 and not a.sharded:
         vol = torch.empty((n, n, n), device="cuda")
         hip.synth_lattice(vol, 0, 11)
         torch.cuda.synchronize()
@@ -177,7 +180,7 @@ def main():
         pyr_time = lambda: det.timings()["gauss_dev"]  # noqa: E731
     else:
         from sift3d_amd import sharded
-        job = sharded.ShardedSift3D(n, n, n * world, dist.group.WORLD)
+        job = sharded.ShardedSift3D(n, n, n * world, dist.group.WORLD if world > 1 else None)
         job.synth(seed=11)
         step = job.step
         voxels_per_step = n ** 3 * world
@@ -238,7 +241,7 @@ def main():
             traffic = json.load(open(tpath))
         except Exception:
             traffic = None
-    if world == 1 and not a.no_micro:
+    if world == 1 and not a.no_micro and not a.sharded:
         kb = kernel_microbench(torch, hip, n)
         # dominant kernel = the pipeline kernel with the longest launch
         dom = max((k for k in kb if k["in_pipeline"]), key=lambda k: k["avg_ms"])

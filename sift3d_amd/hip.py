@@ -101,9 +101,18 @@ def _check(rc, what):
         raise RuntimeError("%s failed: %s" % (what, lib().sift3d_hip_last_error().decode()))
 
 
-def current_stream():
-    import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_stream = None
+
+
+def current_stream(refresh=False):
+    """torch's current HIP stream as a void*.  Looked up once and cached (the query costs
+    ~0.1 ms of host time, far more than a kernel launch); call current_stream(refresh=True)
+    after switching torch's current stream."""
+    global _stream
+    if _stream is None or refresh:
+        import torch
+        _stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _stream
 
 
 def fir(src, dst, axis, taps, unit_factor=1.0, n_glob=None, off=0, z_lo=0, z_hi=None, variant=0):

@@ -32,9 +32,9 @@ import numpy as np
 
 KP_DTYPE = np.dtype([("R", "f4", (3, 3)), ("xd", "f8"), ("yd", "f8"), ("zd", "f8"),
                      ("sd", "f8"), ("o", "i4"), ("s", "i4"), ("strength", "f4")])
-# candidate record as exchanged between ranks (global coordinates)
-GCAND_DTYPE = np.dtype([("o", "i4"), ("s", "i4"), ("x", "i4"), ("y", "i4"), ("z", "i4"),
-                        ("val", "f4"), ("keep", "i4"), ("R", "f4", (9,))])
+# oriented keypoint as exchanged between ranks (global coordinates)
+GKP_DTYPE = np.dtype([("o", "i4"), ("s", "i4"), ("x", "i4"), ("y", "i4"), ("z", "i4"),
+                      ("R", "f4", (9,))])
 
 WINDOW_HALO = 40   # planes: ceil(2 * 7.0711 * 1.6 * 2^(2/3)) + 1 (gradient) + slack
 MIN_SLAB = 48      # a sharded octave keeps at least this many planes per rank
@@ -156,6 +156,10 @@ class HipBackend:
                 self._cand = torch.empty(self._cap * 12, dtype=torch.uint8, device="cuda")
                 self._R = torch.empty((self._cap, 9), dtype=torch.float32, device="cuda")
                 self._keep = torch.empty(self._cap, dtype=torch.int32, device="cuda")
+                # page-locked mirrors: the three read-backs run as plain DMA, one sync
+                self._cand_h = torch.empty(self._cap * 12, dtype=torch.uint8, pin_memory=True)
+                self._R_h = torch.empty((self._cap, 9), dtype=torch.float32, pin_memory=True)
+                self._keep_h = torch.empty(self._cap, dtype=torch.int32, pin_memory=True)
             self._count.zero_()
             for lv, nx, ny, nz in specs:
                 arr = (hip.ExtremaLevel * len(lv))()
@@ -177,8 +181,12 @@ class HipBackend:
         hip._check(L.sift3d_hip_orient(table.data_ptr(), self._cand.data_ptr(), n, float(corner),
                                        self._R.data_ptr(), self._keep.data_ptr(),
                                        hip.current_stream()), "sift3d_hip_orient")
-        cands = self._cand[:n * 12].cpu().numpy().view(hip.CAND_DTYPE)
-        return cands, self._R[:n].cpu().numpy(), self._keep[:n].cpu().numpy()
+        self._cand_h[:n * 12].copy_(self._cand[:n * 12], non_blocking=True)
+        self._R_h[:n].copy_(self._R[:n], non_blocking=True)
+        self._keep_h[:n].copy_(self._keep[:n], non_blocking=True)
+        torch.cuda.synchronize()
+        return (self._cand_h[:n * 12].numpy().view(hip.CAND_DTYPE), self._R_h[:n].numpy(),
+                self._keep_h[:n].numpy())
 
     def describe(self, table, kps):
         torch, hip = self.torch, self.hip
@@ -362,6 +370,31 @@ class ShardedSift3D:
         dist.all_gather(outs, mine, group=self.group)
         return [o.cpu().numpy()[:c * item].view(recs.dtype).copy() for o, c in zip(outs, counts)]
 
+    def _allgather_fixed(self, arr):
+        """all-gather of equally shaped numpy arrays -> stacked [world, ...]."""
+        if self.world == 1:
+            return arr[None]
+        torch, dist = self.torch, self.dist
+        dev = "cpu" if self._is_gloo() else self.be.device
+        mine = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+        outs = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(outs, mine, group=self.group)
+        return np.stack([o.cpu().numpy() for o in outs])
+
+    def _allgather_padded(self, recs, counts):
+        """all-gather-v when every rank already knows all lengths -> list per rank."""
+        if self.world == 1:
+            return [recs]
+        torch, dist = self.torch, self.dist
+        dev = "cpu" if self._is_gloo() else self.be.device
+        item = recs.dtype.itemsize
+        buf = np.zeros(max(max(counts), 1) * item, np.uint8)
+        buf[:len(recs) * item] = np.ascontiguousarray(recs).view(np.uint8).reshape(-1)
+        mine = torch.from_numpy(buf).to(dev)
+        outs = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(outs, mine, group=self.group)
+        return [o.cpu().numpy()[:c * item].view(recs.dtype) for o, c in zip(outs, counts)]
+
     def _gather_level(self, lv_src, dst):
         """all-gather the owned planes of a sharded level into the replicated tensor dst."""
         torch, dist = self.torch, self.dist
@@ -532,43 +565,57 @@ class ShardedSift3D:
                                              sd=self._scale(o, s - 1)))
             self._table = be.level_table(table_levels)
         local, R, keep = be.extrema_orient(specs, self._table, self.peak, self.corner)
-        # to global records (vectorised over all octaves)
-        oct_ = (local["tag"] // g.ngl).astype(np.int64)
+        # Exchange (all-gather-v): per-(o,s) counts, the candidates' |DoG| values and
+        # the ORIENTED keypoints only -- the rejected candidates' records stay on their rank.
+        nkey = g.num_octaves * g.K
+        tag = local["tag"].astype(np.int64)
+        oct_ = tag // g.ngl
+        key = oct_ * g.K + (tag % g.ngl - 1)        # non-decreasing: extrema emit in (o, s) order
+        km = keep != 0
+        cnt = np.stack([np.bincount(key, minlength=nkey), np.bincount(key[km], minlength=nkey)], 1)
+        lk, ok_ = local[km], oct_[km]
         dims = np.array(g.dims, np.int64)
         offs = np.array([self.D[o][0].off for o in range(g.num_octaves)], np.int64)
-        idx = local["idx"].astype(np.int64)
-        nxv, nyv = dims[oct_, 0], dims[oct_, 1]
-        out = np.zeros(len(local), GCAND_DTYPE)
-        out["o"] = oct_
-        out["s"] = local["tag"] % g.ngl - 1
-        out["x"] = idx % nxv
-        out["y"] = (idx // nxv) % nyv
-        out["z"] = idx // (nxv * nyv) + offs[oct_]
-        out["val"] = local["val"]
-        out["keep"] = keep
-        out["R"] = R
-        parts = self._allgather_records(out)
-        # global order: (o, s) major, then ranks in slab order (their z ranges are disjoint
-        # and ascending), each rank's list already in (z, y, x) order
+        idx = lk["idx"].astype(np.int64)
+        nxv, nyv = dims[ok_, 0], dims[ok_, 1]
+        rec = np.zeros(len(lk), GKP_DTYPE)
+        rec["o"] = ok_
+        rec["s"] = lk["tag"] % g.ngl - 1
+        rec["x"] = idx % nxv
+        rec["y"] = (idx // nxv) % nyv
+        rec["z"] = idx // (nxv * nyv) + offs[ok_]
+        rec["R"] = R[km]
+        cnts = self._allgather_fixed(cnt.astype(np.int64))          # [world, nkey, 2]
+        vals = self._allgather_padded(np.ascontiguousarray(local["val"]), cnts[:, :, 0].sum(1))
+        recs = self._allgather_padded(rec, cnts[:, :, 1].sum(1))
+        # global order: (o, s) major, then ranks in slab order (their z ranges are disjoint and
+        # ascending), each rank's list already in (z, y, x) order
         if self.world > 1:
-            # every rank's list is sorted by (o, s): cut it at the (o, s) boundaries
-            nkey = g.num_octaves * g.K
-            cuts = [np.searchsorted(p["o"].astype(np.int64) * g.K + p["s"], np.arange(nkey + 1))
-                    for p in parts]
-            chunks = [p[c[k]:c[k + 1]] for k in range(nkey) for p, c in zip(parts, cuts)]
-            allc = np.concatenate(chunks) if chunks else out
+            cc = np.concatenate([np.zeros((self.world, 1), np.int64), np.cumsum(cnts[:, :, 0], 1)], 1)
+            ck = np.concatenate([np.zeros((self.world, 1), np.int64), np.cumsum(cnts[:, :, 1], 1)], 1)
+            kept = np.concatenate([recs[r][ck[r, k]:ck[r, k + 1]]
+                                   for k in range(nkey) for r in range(self.world)])
+            # copy_Keypoint omits `strength` (sift.c:372-384): slot j keeps CANDIDATE j's value
+            # (Q2), so only the first len(kept) values of the global candidate order matter
+            need, got, chunks = len(kept), 0, []
+            for k in range(nkey):
+                for r in range(self.world):
+                    if got >= need:
+                        break
+                    c = vals[r][cc[r, k]:cc[r, k + 1]]
+                    chunks.append(c)
+                    got += len(c)
+            val_head = np.concatenate(chunks)[:need] if chunks else np.zeros(0, np.float32)
         else:
-            allc = out
-        self.ncand = len(allc)
-        kept = allc[allc["keep"] != 0]
+            kept, val_head = rec, local["val"][:len(rec)]
+        self.ncand = int(cnts[:, :, 0].sum())
         kp = np.zeros(len(kept), KP_DTYPE)
         kp["o"], kp["s"] = kept["o"], kept["s"]
         kp["xd"], kp["yd"], kp["zd"] = kept["x"], kept["y"], kept["z"]
         sd_tab = np.array([[self._scale(o, s) for s in range(g.K)] for o in range(g.num_octaves)])
         kp["sd"] = sd_tab[kept["o"], kept["s"]] if len(kept) else 0.0
         kp["R"] = kept["R"].reshape(-1, 3, 3)
-        # copy_Keypoint omits `strength` (sift.c:372-384): slot j keeps candidate j's (Q2)
-        kp["strength"] = allc["val"][:len(kept)]
+        kp["strength"] = val_head
         self.kp = kp
         self.t_pyr = be.elapsed(*self._ev)
         return kp
@@ -609,6 +656,8 @@ class ShardedSift3D:
 
     # ---- bench hooks ---------------------------------------------------------------------------
     def step(self):
+        if hasattr(self.be, "hip"):
+            self.be.hip.current_stream(refresh=True)
         self.detect()
         self.describe()
 
