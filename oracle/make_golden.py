@@ -181,6 +181,52 @@ def end_to_end(name, vol, units=(1, 1, 1), full_levels_below=17, desc_stride=1, 
                        t_detect=round(t_detect, 2), t_describe=round(t_desc, 2))}
 
 
+def end_to_end_digest(name, vol, stride=97, input_spec=None):
+    """Full-size case: the reference's results as sha1 digests plus strided samples (small file)."""
+    p = refprobe.Probe()
+    t0 = time.time()
+    assert p.detect(vol, (1, 1, 1)) == 0
+    t_detect = time.time() - t0
+    d = {"dims": np.array(vol.shape[::-1], np.int32), "input_digest": np.array(digest(vol)),
+         "num_octaves": np.array(p.num_octaves), "stride": np.array(stride)}
+    dig = {}
+    for o in range(p.num_octaves):
+        for which, n in ((0, 6), (1, 5)):
+            for s in range(-1, n - 1):
+                a, _, _ = p.level(which, o, s)
+                dig["%s_o%d_s%d" % ("G" if which == 0 else "D", o, s)] = digest(a)
+    c = p.candidates()
+    k = p.keypoints()
+    d["ncand"] = np.array(len(c["sd"]))
+    d["nkp"] = np.array(len(k["strength"]))
+    dig["cand_osxyz"] = digest(np.ascontiguousarray(c["osxyz"]))
+    dig["kp_os"] = digest(np.ascontiguousarray(k["os"]))
+    dig["kp_xyzsd"] = digest(np.ascontiguousarray(k["xyzsd"]))
+    dig["kp_strength"] = digest(np.ascontiguousarray(k["strength"]))
+    dig["kp_R"] = digest(np.ascontiguousarray(k["R"]))
+    d["kp_idx"] = np.arange(0, len(k["strength"]), stride, dtype=np.int32)
+    d["kp_os_s"] = k["os"][::stride]
+    d["kp_xyzsd_s"] = k["xyzsd"][::stride]
+    d["kp_strength_s"] = k["strength"][::stride]
+    d["kp_R_s"] = k["R"][::stride]
+    t0 = time.time()
+    assert p.describe() == 0
+    t_desc = time.time() - t0
+    h, x = p.descriptors()
+    dig["desc_hist"] = digest(np.ascontiguousarray(h))
+    d["desc_hist_s"] = h[::stride]
+    d["desc_rowsum"] = h.astype(np.float64).sum(axis=1).astype(np.float32)
+    d["digests"] = np.array(json.dumps(dig))
+    if input_spec:
+        d["input_spec"] = np.array(json.dumps(input_spec))
+    d["ref_time_detect_s"] = np.array(t_detect)
+    d["ref_time_describe_s"] = np.array(t_desc)
+    p.close()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    return {name: dict(cand=int(d["ncand"]), kp=int(d["nkp"]), t_detect=round(t_detect, 2),
+                       t_describe=round(t_desc, 2))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also 128^3 and 256^3 (minutes)")
@@ -214,6 +260,10 @@ def main():
         jobs["g5_256"] = lambda: end_to_end(
             "g5_256", so.synth_survey(256), desc_stride=64, store_levels=False,
             input_spec=dict(gen="survey", n=256, nblob=12800))
+    if a.only and "g5_512" in a.only.split(","):
+        # BASELINE configs[2] (the bench workload): ~10 min of reference CPU time, ~10 GB
+        jobs["g5_512"] = lambda: end_to_end_digest(
+            "g5_512", so.synth_lattice(512, seed=11), input_spec=dict(gen="lattice", n=512, seed=11))
     for k, fn in jobs.items():
         if a.only and k not in a.only.split(","):
             continue

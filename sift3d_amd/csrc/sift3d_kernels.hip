@@ -1980,7 +1980,7 @@ __global__ __launch_bounds__(256) void k_synth_lattice(float *__restrict__ dst, 
                 const float q = dx * dx + 1.3f * dy * dy + 0.7f * dz * dz;
                 if (q > 18.0f * sg * sg)
                     continue;
-                v += a * expf(-q / (2.0f * sg * sg));
+                v += a * s3d_expf(-q / (2.0f * sg * sg));   // == the host twin's libm expf, bit for bit
             }
     dst[(size_t)x + (size_t)nx * ((size_t)y + (size_t)ny * zl)] = v;
 }
