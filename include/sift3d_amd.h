@@ -46,6 +46,12 @@ sift3d_amd_detect_keypoints_device(sift3d_detector *det, const float *d_volume,
 SIFT3D_AMD_API int
 sift3d_amd_image_set_units(sift3d_image *im, double ux, double uy, double uz);
 
+/* Extremum neighbourhood of the following detect calls: 0 (default) = the default build's
+ * 8-neighbour test, non-zero = the reference's compile-time CUBOID_EXTREMA variant
+ * (sift.c:24, 761-796), here a run-time option. */
+SIFT3D_AMD_API int
+sift3d_amd_detector_set_cuboid_extrema(sift3d_detector *det, int on);
+
 /* Wall-clock seconds of the stages of the last detect/describe on `det`:
  * [0] upload+scale  [1] Gaussian pyramid  [2] DoG  [3] extrema  [4] orientation
  * [5] describe  [6] pyramid kernels only, device time from HIP events
@@ -217,6 +223,14 @@ SIFT3D_AMD_API int
 sift3d_hip_extrema(const sift3d_hip_extrema_level *levels, int nlevels, int nx, int ny,
                    int nz, double peak_thresh, sift3d_hip_cand *d_out, uint32_t cap,
                    uint32_t *d_count, void *d_work, size_t work_bytes, void *stream);
+
+/* The same with the neighbourhood selectable: cuboid = 0 is the default build's 8-neighbour test
+ * (sift.c:797-810), cuboid = 1 the reference's compile-time CUBOID_EXTREMA variant
+ * (sift.c:24, 761-796: 27 + 26 + 27 samples). */
+SIFT3D_AMD_API int
+sift3d_hip_extrema_mode(const sift3d_hip_extrema_level *levels, int nlevels, int nx, int ny, int nz,
+                        double peak_thresh, int cuboid, sift3d_hip_cand *d_out, uint32_t cap,
+                        uint32_t *d_count, void *d_work, size_t work_bytes, void *stream);
 
 /* Geometry of one Gaussian level, as the window kernels see it (a table of these
  * lives in device memory, indexed by the `tag`/`level` of a record). */

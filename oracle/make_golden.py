@@ -250,6 +250,13 @@ def main():
                                     params=dict(num_kp_levels=2, sigma0=2.0, sigma_n=1.0,
                                                 peak_thresh=0.05, corner_thresh=0.3),
                                     input_spec=dict(gen="survey", n=32)),
+        "g3_cub": lambda: end_to_end("g3_cuboid64", so.synth_survey(64),
+                                     params=dict(cuboid_extrema=True),
+                                     input_spec=dict(gen="survey", n=64, nblob=200)),
+        "g3_cubp": lambda: end_to_end("g3_cuboid_params", so.synth_lattice((50, 44, 40), seed=9),
+                                      params=dict(cuboid_extrema=True, peak_thresh=0.03,
+                                                  corner_thresh=0.2),
+                                      input_spec=dict(gen="lattice", n=[50, 44, 40], seed=9)),
         "g3_lat": lambda: end_to_end("g3_lattice48", so.synth_lattice(48, seed=7),
                                      input_spec=dict(gen="lattice", n=48, seed=7)),
     }

@@ -12,6 +12,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_ref", "libsift3d_refprobe.so")
+# the same sources compiled with -DCUBOID_EXTREMA (sift.c:24)
+LIB_PATH_CUBOID = os.path.join(HERE, "_ref", "libsift3d_refprobe_cuboid.so")
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -22,13 +24,12 @@ def available():
     return os.path.exists(LIB_PATH)
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        L = C.CDLL(LIB_PATH)
+def lib(cuboid=False):
+    if cuboid not in _libs:
+        L = C.CDLL(LIB_PATH_CUBOID if cuboid else LIB_PATH)
         L.probe_gauss_filter.argtypes = [C.c_double, _f32p, C.c_int]
         L.probe_apply_sep_fir.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int,
                                           C.c_double, C.c_double, C.c_double,
@@ -65,8 +66,8 @@ def lib():
                   "sift3d_detector_set_sigma_n", "sift3d_detector_set_sigma0"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_double]
         L.sift3d_detector_set_num_kp_levels.argtypes = [C.c_void_p, C.c_uint]
-        _lib = L
-    return _lib
+        _libs[cuboid] = L
+    return _libs[cuboid]
 
 
 def gauss_filter(sigma):
@@ -118,8 +119,8 @@ class Probe:
     """One reference detector + stores, with stage dumps."""
 
     def __init__(self, peak_thresh=None, corner_thresh=None, num_kp_levels=None,
-                 sigma_n=None, sigma0=None):
-        self.L = lib()
+                 sigma_n=None, sigma0=None, cuboid_extrema=False):
+        self.L = lib(bool(cuboid_extrema))
         self.h = self.L.probe_make()
         det = self.L.probe_detector(self.h)
         if sigma_n is not None:

@@ -72,6 +72,7 @@ struct orc_ctx {
     double peak_thresh, corner_thresh, sigma_n, sigma0;
     int num_kp_levels;
     int fir_mode;
+    int cuboid;             /* CUBOID_EXTREMA switch */
     /* scaled input copy (sift.c:645-649) */
     orc_level_t im;
     int have_im;
@@ -574,6 +575,9 @@ void orc_destroy(orc_ctx *c)
 
 void orc_set_fir_mode(orc_ctx *c, int mode) { c->fir_mode = mode; }
 
+/* CUBOID_EXTREMA (sift.c:24) as a switch: 0 = default build, 1 = 80-neighbour test */
+void orc_set_cuboid_extrema(orc_ctx *c, int on) { c->cuboid = on ? 1 : 0; }
+
 static double level_scale(const orc_ctx *c, int o, int s)
 {
     /* set_scales_Pyramid, imutil.c:1578-1579 */
@@ -823,7 +827,27 @@ int orc_build_pyramids(orc_ctx *c)
     return ORC_SUCCESS;
 }
 
-/* detect_extrema, sift.c:735-871 (default build: 8 neighbours, D2) */
+/* CMP_CUBE over prev / cur (self ignored) / next, sift.c:761-796 */
+static int cuboid_extremum(const float *pv, const float *cv, const float *nv, size_t p, size_t ys,
+                           size_t zs, float v)
+{
+    int gt = 1, lt = 1, dx, dy, dz;
+    for (dz = -1; dz <= 1; dz++)
+        for (dy = -1; dy <= 1; dy++)
+            for (dx = -1; dx <= 1; dx++) {
+                const size_t q = (size_t)((long)p + dx + (long)ys * dy + (long)zs * dz);
+                gt = gt && v > pv[q] && v > nv[q];
+                lt = lt && v < pv[q] && v < nv[q];
+                if (dx || dy || dz) {
+                    gt = gt && v > cv[q];
+                    lt = lt && v < cv[q];
+                }
+            }
+    return gt || lt;
+}
+
+/* detect_extrema, sift.c:735-871 (default build: 8 neighbours, D2; c->cuboid: the
+ * CUBOID_EXTREMA build) */
 int orc_find_extrema(orc_ctx *c)
 {
     int o, s;
@@ -854,6 +878,10 @@ int orc_find_extrema(orc_ctx *c)
                         const float v = cv[p];
                         if (!(v > thr || v < -thr))         /* sift.c:842 */
                             continue;
+                        if (c->cuboid) {
+                            if (!cuboid_extremum(pv, cv, nv, p, ys, zs, v))
+                                continue;
+                        } else
                         if (!((v > pv[p] && v > cv[p + 1] && v > cv[p - 1] &&
                                v > cv[p + ys] && v > cv[p - ys] && v > cv[p - zs] &&
                                v > cv[p + zs] && v > nv[p]) ||

@@ -76,6 +76,7 @@ def lib():
             getattr(L, n).argtypes = [C.c_void_p, C.c_double]
         L.orc_set_num_kp_levels.argtypes = [C.c_void_p, C.c_uint]
         L.orc_set_fir_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_cuboid_extrema.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_volume.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_double]
         L.orc_detect.argtypes = L.orc_set_volume.argtypes
@@ -175,10 +176,11 @@ def synth_lattice(n, seed=1):
 
 class Oracle:
     def __init__(self, peak_thresh=None, corner_thresh=None, num_kp_levels=None,
-                 sigma_n=None, sigma0=None, fir_mode=1):
+                 sigma_n=None, sigma0=None, fir_mode=1, cuboid_extrema=False):
         self.L = lib()
         self.h = self.L.orc_create()
         self.L.orc_set_fir_mode(self.h, fir_mode)
+        self.L.orc_set_cuboid_extrema(self.h, int(bool(cuboid_extrema)))
         if sigma_n is not None:
             assert self.L.orc_set_sigma_n(self.h, sigma_n) == 0
         if sigma0 is not None:

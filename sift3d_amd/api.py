@@ -70,6 +70,7 @@ def lib():
         "sift3d_amd_image_set_units": (C.c_int, [vp, C.c_double, C.c_double, C.c_double]),
         "sift3d_amd_timings": (C.POINTER(C.c_double), [vp]),
         "sift3d_amd_num_candidates": (C.c_int, [vp]),
+        "sift3d_amd_detector_set_cuboid_extrema": (C.c_int, [vp, C.c_int]),
         "sift3d_amd_copy_level": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, _i32p]),
         "sift3d_amd_keypoint_store_size": (C.c_int, [vp]),
         "sift3d_amd_keypoint_store_get": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int),
@@ -252,12 +253,13 @@ class Detector:
     """sift3d_detector (reference: sift3d/sift.h:24-111)."""
 
     def __init__(self, peak_thresh=None, corner_thresh=None, num_kp_levels=None, sigma_n=None,
-                 sigma0=None):
+                 sigma0=None, cuboid_extrema=None):
         self.h = lib().sift3d_make_detector()
         if not self.h:
             raise MemoryError("sift3d_make_detector")
         for name, v in (("sigma_n", sigma_n), ("sigma0", sigma0), ("peak_thresh", peak_thresh),
-                        ("corner_thresh", corner_thresh), ("num_kp_levels", num_kp_levels)):
+                        ("corner_thresh", corner_thresh), ("num_kp_levels", num_kp_levels),
+                        ("cuboid_extrema", cuboid_extrema)):
             if v is not None and getattr(self, "set_" + name)(v) != 0:
                 raise ValueError("sift3d_detector_set_%s(%r) failed" % (name, v))
 
@@ -282,6 +284,10 @@ class Detector:
 
     def set_sigma0(self, v):
         return lib().sift3d_detector_set_sigma0(self.h, float(v))
+
+    def set_cuboid_extrema(self, on):
+        """Run-time form of the reference's compile-time CUBOID_EXTREMA (sift.c:24)."""
+        return lib().sift3d_amd_detector_set_cuboid_extrema(self.h, int(bool(on)))
 
     def detect_keypoints(self, image, store):
         return lib().sift3d_detect_keypoints(self.h, image.h, store.h)

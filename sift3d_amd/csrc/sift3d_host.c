@@ -95,6 +95,7 @@ typedef struct {
 struct _sift3d_detector {
     /* parameters (sift.c:499-565) */
     double peak_thresh, corner_thresh, sigma_n, sigma0;
+    int cuboid_extrema;     /* 0: 8-neighbour test (default build), 1: CUBOID_EXTREMA, sift.c:24 */
     int num_kp_levels;
     /* image geometry */
     int have_im;
@@ -803,6 +804,14 @@ int sift3d_detector_set_peak_thresh(sift3d_detector *const d, const double v)
     return SIFT3D_SUCCESS;
 }
 
+int sift3d_amd_detector_set_cuboid_extrema(sift3d_detector *d, int on)
+{
+    if (!d)
+        return SIFT3D_FAILURE;
+    d->cuboid_extrema = on ? 1 : 0;
+    return SIFT3D_SUCCESS;
+}
+
 int sift3d_detector_set_corner_thresh(sift3d_detector *const d, const double v)
 {
     if (v < 0.0 || v > 1.0) {                        /* sift.c:515-519 */
@@ -1131,8 +1140,8 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                 lv[s].z_hi = d->odims[o][2] - 1;
                 lv[s].tag = o * d->ngl + s + 1;      /* Gaussian level (o, s) of the table */
             }
-            if (sift3d_hip_extrema(lv, nl, d->odims[o][0], d->odims[o][1], d->odims[o][2],
-                                   d->peak_thresh, d->d_cand, d->cand_cap,
+            if (sift3d_hip_extrema_mode(lv, nl, d->odims[o][0], d->odims[o][1], d->odims[o][2],
+                                   d->peak_thresh, d->cuboid_extrema, d->d_cand, d->cand_cap,
                                    (uint32_t *)(d->d_scalars + 1), d->d_work, d->work_bytes,
                                    d->stream))
                 return SIFT3D_FAILURE;

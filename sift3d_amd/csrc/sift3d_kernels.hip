@@ -1148,7 +1148,35 @@ struct ExGeom {
     uint32_t nwords;// nz * ny * wpr
     uint32_t nblk;  // ceil(nwords / EX_WPB)
     double peak_thresh;
+    int cuboid;     // 1: the reference's CUBOID_EXTREMA build (80 neighbours, sift.c:761-796)
 };
+
+// CMP_CUBE of the CUBOID_EXTREMA build (sift.c:761-796): strictly above (or strictly below) all
+// 27 samples of the previous and next DoG level and the 26 neighbours in the current one
+__device__ __forceinline__ bool cuboid_extremum(const float *__restrict__ prev,
+                                                const float *__restrict__ cur,
+                                                const float *__restrict__ next, size_t q, size_t ys,
+                                                size_t zs, float c)
+{
+    bool gt = true, lt = true;
+#pragma unroll
+    for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+            for (int dx = -1; dx <= 1; dx++) {
+                const size_t r = q + dx + ys * dy + zs * dz;
+                const float a = prev[r], b = next[r];
+                gt = gt && c > a && c > b;
+                lt = lt && c < a && c < b;
+                if (dx || dy || dz) {
+                    const float m = cur[r];
+                    gt = gt && c > m;
+                    lt = lt && c < m;
+                }
+            }
+    return gt || lt;
+}
 
 __global__ __launch_bounds__(256) void k_extrema_mask(ExLevels LV, ExGeom E,
                                                       unsigned long long *__restrict__ masks,
@@ -1193,7 +1221,10 @@ __global__ __launch_bounds__(256) void k_extrema_mask(ExLevels LV, ExGeom E,
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 bool hit = false;
-                if (ok[k] && (v[k] > thr || v[k] < -thr)) {              // sift.c:842
+                if (E.cuboid) {
+                    if (ok[k] && (v[k] > thr || v[k] < -thr))            // sift.c:842
+                        hit = cuboid_extremum(L.prev, L.cur, L.next, p[k], ys, zs, v[k]);
+                } else if (ok[k] && (v[k] > thr || v[k] < -thr)) {       // sift.c:842
                     const size_t q = p[k];
                     const float c = v[k];
                     const float n0 = L.prev[q], n1 = L.cur[q + 1], n2 = L.cur[q - 1],
@@ -2409,9 +2440,10 @@ int sift3d_hip_downsample2(const float *d_src, int nx, int ny, float *d_dst, int
     return SIFT3D_SUCCESS;
 }
 
-static ExGeom ex_geom(int nx, int ny, int nz, double peak)
+static ExGeom ex_geom(int nx, int ny, int nz, double peak, int cuboid = 0)
 {
     ExGeom E;
+    E.cuboid = cuboid;
     E.nx = nx; E.ny = ny; E.nz = nz;
     E.wpr = (nx + 63) / 64;
     E.nwords = (uint32_t)((size_t)nz * ny * E.wpr);
@@ -2430,6 +2462,15 @@ int sift3d_hip_extrema(const sift3d_hip_extrema_level *levels, int nlevels, int 
                        double peak_thresh, sift3d_hip_cand *d_out, uint32_t cap, uint32_t *d_count,
                        void *d_work, size_t work_bytes, void *stream)
 {
+    return sift3d_hip_extrema_mode(levels, nlevels, nx, ny, nz, peak_thresh, 0, d_out, cap, d_count,
+                                   d_work, work_bytes, stream);
+}
+
+int sift3d_hip_extrema_mode(const sift3d_hip_extrema_level *levels, int nlevels, int nx, int ny,
+                            int nz, double peak_thresh, int cuboid, sift3d_hip_cand *d_out,
+                            uint32_t cap, uint32_t *d_count, void *d_work, size_t work_bytes,
+                            void *stream)
+{
     hipStream_t st = (hipStream_t)stream;
     if (nlevels < 1 || nlevels > 8 || (size_t)nx * ny * nz >= (1ull << 32) ||
         work_bytes < sift3d_hip_extrema_work_bytes(nx, ny, nz, nlevels)) {
@@ -2437,7 +2478,7 @@ int sift3d_hip_extrema(const sift3d_hip_extrema_level *levels, int nlevels, int 
         fprintf(stderr, "sift3d_amd: %s\n", g_err);
         return SIFT3D_FAILURE;
     }
-    const ExGeom E = ex_geom(nx, ny, nz, peak_thresh);
+    const ExGeom E = ex_geom(nx, ny, nz, peak_thresh, cuboid ? 1 : 0);
     ExLevels LV;
     memset(&LV, 0, sizeof(LV));
     for (int i = 0; i < nlevels; i++)

@@ -80,6 +80,8 @@ def lib():
         "sift3d_hip_extrema_work_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
         "sift3d_hip_extrema": (C.c_int, [C.POINTER(ExtremaLevel), C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_double, vp, C.c_uint32, vp, vp, C.c_size_t, vp]),
+        "sift3d_hip_extrema_mode": (C.c_int, [C.POINTER(ExtremaLevel), C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_double, C.c_int, vp, C.c_uint32, vp, vp, C.c_size_t, vp]),
         "sift3d_hip_orient": (C.c_int, [vp, vp, C.c_uint32, C.c_double, vp, vp, vp]),
         "sift3d_hip_describe": (C.c_int, [vp, vp, C.c_uint32, vp, vp]),
         "sift3d_hip_set_mesh": (C.c_int, [C.POINTER(C.c_float)]),
@@ -201,7 +203,7 @@ def level_table(levels):
     return dev, tab
 
 
-def extrema(levels, nx, ny, nz, peak_thresh, cap=1 << 18):
+def extrema(levels, nx, ny, nz, peak_thresh, cap=1 << 18, cuboid=False):
     """levels: list of dict(prev, cur, next (tensors), absmax (1-elem tensor), z_lo, z_hi, tag).
     Returns CAND_DTYPE records in the reference's scan order."""
     import torch
@@ -216,9 +218,10 @@ def extrema(levels, nx, ny, nz, peak_thresh, cap=1 << 18):
     while True:
         out = torch.empty(cap * CAND_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
         count.zero_()
-        _check(L.sift3d_hip_extrema(arr, len(levels), nx, ny, nz, float(peak_thresh), out.data_ptr(),
-                                    cap, count.data_ptr(), work.data_ptr(), wb, current_stream()),
-               "sift3d_hip_extrema")
+        _check(L.sift3d_hip_extrema_mode(arr, len(levels), nx, ny, nz, float(peak_thresh),
+                                         int(bool(cuboid)), out.data_ptr(), cap, count.data_ptr(),
+                                         work.data_ptr(), wb, current_stream()),
+               "sift3d_hip_extrema_mode")
         n = int(count.item())
         if n <= cap:
             break

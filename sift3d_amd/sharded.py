@@ -139,7 +139,7 @@ class HipBackend:
     def level_table(self, levels):
         return self.hip.level_table(levels)[0]
 
-    def extrema_orient(self, specs, table, peak, corner):
+    def extrema_orient(self, specs, table, peak, corner, cuboid=False):
         """detect_extrema for every octave (one shared candidate buffer, device-side running
         count, a single host sync) followed by assign_orientations on the device-resident
         candidates.  specs: [(levels, nx, ny, nz_local)].  Returns host arrays (cands, R, keep)."""
@@ -167,11 +167,12 @@ class HipBackend:
                     arr[i] = hip.ExtremaLevel(l["prev"].data_ptr(), l["cur"].data_ptr(),
                                               l["next"].data_ptr(), l["absmax"].data_ptr(),
                                               l["z_lo"], l["z_hi"], l["tag"])
-                hip._check(L.sift3d_hip_extrema(arr, len(lv), nx, ny, nz, float(peak),
-                                                self._cand.data_ptr(), self._cap,
-                                                self._count.data_ptr(), self._work.data_ptr(),
-                                                self._work.numel(), hip.current_stream()),
-                           "sift3d_hip_extrema")
+                hip._check(L.sift3d_hip_extrema_mode(arr, len(lv), nx, ny, nz, float(peak),
+                                                     int(bool(cuboid)), self._cand.data_ptr(),
+                                                     self._cap, self._count.data_ptr(),
+                                                     self._work.data_ptr(), self._work.numel(),
+                                                     hip.current_stream()),
+                           "sift3d_hip_extrema_mode")
             n = int(self._count.item())
             if n <= self._cap:
                 break
@@ -237,7 +238,8 @@ class _Level:
 
 class ShardedSift3D:
     def __init__(self, nx, ny, nz, group=None, backend=None, peak_thresh=0.1, corner_thresh=0.4,
-                 num_kp_levels=3, sigma_n=1.15, sigma0=1.6, units=(1.0, 1.0, 1.0)):
+                 num_kp_levels=3, sigma_n=1.15, sigma0=1.6, units=(1.0, 1.0, 1.0),
+                 cuboid_extrema=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -246,6 +248,7 @@ class ShardedSift3D:
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.be = backend if backend is not None else HipBackend()
         self.peak, self.corner = float(peak_thresh), float(corner_thresh)
+        self.cuboid = bool(cuboid_extrema)   # CUBOID_EXTREMA (sift.c:24) as a run-time option
         self.sigma_n, self.sigma0 = float(sigma_n), float(sigma0)
         self.units = tuple(float(u) for u in units)
         self.g = Geometry(nx, ny, nz, self.world, num_kp_levels)
@@ -564,7 +567,7 @@ class ShardedSift3D:
                                              units=self._lunits(o), octave=o,
                                              sd=self._scale(o, s - 1)))
             self._table = be.level_table(table_levels)
-        local, R, keep = be.extrema_orient(specs, self._table, self.peak, self.corner)
+        local, R, keep = be.extrema_orient(specs, self._table, self.peak, self.corner, self.cuboid)
         # Exchange (all-gather-v): per-(o,s) counts, the candidates' |DoG| values and
         # the ORIENTED keypoints only -- the rejected candidates' records stay on their rank.
         nkey = g.num_octaves * g.K

@@ -69,7 +69,7 @@ class OracleBackend:
         mz, my, mx = dst.shape
         dst.copy_(src[0:2 * mz:2, 0:2 * my:2, 0:2 * mx:2])
 
-    def extrema(self, levels, nx, ny, nz, peak):
+    def extrema(self, levels, nx, ny, nz, peak, cuboid=False):
         recs = []
         for lv in levels:
             p, c, n = lv["prev"].numpy(), lv["cur"].numpy(), lv["next"].numpy()
@@ -81,6 +81,10 @@ class OracleBackend:
             nb = [p[zl:zh, 1:-1, 1:-1], n[zl:zh, 1:-1, 1:-1], c[zl:zh, 1:-1, 2:], c[zl:zh, 1:-1, :-2],
                   c[zl:zh, 2:, 1:-1], c[zl:zh, :-2, 1:-1], c[zl - 1:zh - 1, 1:-1, 1:-1],
                   c[zl + 1:zh + 1, 1:-1, 1:-1]]
+            if cuboid:                                                # sift.c:761-796
+                nb = [a[zl + dz:zh + dz, 1 + dy:a.shape[1] - 1 + dy, 1 + dx:a.shape[2] - 1 + dx]
+                      for a in (p, c, n) for dz in (-1, 0, 1) for dy in (-1, 0, 1)
+                      for dx in (-1, 0, 1) if not (a is c and dz == dy == dx == 0)]
             gt = np.ones(v.shape, bool)
             lt = np.ones(v.shape, bool)
             for q in nb:
@@ -98,8 +102,8 @@ class OracleBackend:
     def level_table(self, levels):
         return levels
 
-    def extrema_orient(self, specs, table, peak, corner):
-        recs = [self.extrema(lv, nx, ny, nz, peak) for lv, nx, ny, nz in specs]
+    def extrema_orient(self, specs, table, peak, corner, cuboid=False):
+        recs = [self.extrema(lv, nx, ny, nz, peak, cuboid) for lv, nx, ny, nz in specs]
         local = np.concatenate(recs) if recs else np.zeros(0, CAND_DTYPE)
         R, keep = self.orient(table, local, corner)
         return local, R, keep

@@ -251,7 +251,7 @@ def _run_api(api, vol, units=(1, 1, 1), params=None, device_input=False):
 
 
 @pytest.mark.parametrize("name", ["g3_64", "g3_70x50x41", "g3_aniso", "g3_params",
-                                  "g3_lattice48", "g5_128"])
+                                  "g3_lattice48", "g5_128", "g3_cuboid64", "g3_cuboid_params"])
 def test_detect_describe_golden(gpu, oracle_mod, name):
     """Against the reference's own outputs: every pyramid level (sha1 digests + small levels
     in full), candidate count, the keypoint list incl. the stale-strength quirk, R,

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, dims, outdir):
+def _worker(rank, world, port, dims, outdir, cuboid=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -34,7 +34,7 @@ def _worker(rank, world, port, dims, outdir):
     try:
         nx, ny, nz = dims
         vol = api.synth_lattice(dims, seed=5)
-        job = sharded.ShardedSift3D(nx, ny, nz, dist.group.WORLD)
+        job = sharded.ShardedSift3D(nx, ny, nz, dist.group.WORLD, cuboid_extrema=cuboid)
         z0, z1 = job.in_own
         job.set_local_volume(torch.from_numpy(vol[z0:z1]).cuda())
         kp = job.detect()
@@ -46,18 +46,19 @@ def _worker(rank, world, port, dims, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dims", [(2, (64, 72, 256)), (3, (48, 48, 160))])
-def test_sharded_hip_equals_single_gpu(world, dims):
+@pytest.mark.parametrize("world,dims,cuboid", [(2, (64, 72, 256), False), (3, (48, 48, 160), False),
+                                               (2, (48, 48, 160), True)])
+def test_sharded_hip_equals_single_gpu(world, dims, cuboid):
     import torch
     import torch.multiprocessing as mp
     from sift3d_amd import api
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no HIP device is visible")
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), dims, d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), dims, d, cuboid), nprocs=world, join=True)
         res = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(world)]
     vol = api.synth_lattice(dims, seed=5)
-    det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+    det, kp, desc = api.Detector(cuboid_extrema=cuboid), api.KeypointStore(), api.DescriptorStore()
     assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
     assert det.extract_descriptors(kp, desc) == 0
     k = kp.records()

@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, dims, outdir):
+def _worker(rank, world, port, dims, outdir, cuboid=False):
     sys.path.insert(0, ROOT)
     os.environ["OMP_NUM_THREADS"] = "2"
     import torch
@@ -39,7 +39,8 @@ def _worker(rank, world, port, dims, outdir):
     try:
         nx, ny, nz = dims
         vol = so.synth_survey(dims, nblob=int(200 * nx * ny * nz / 64 ** 3))
-        job = sharded.ShardedSift3D(nx, ny, nz, dist.group.WORLD, backend=OracleBackend())
+        job = sharded.ShardedSift3D(nx, ny, nz, dist.group.WORLD, backend=OracleBackend(),
+                                    cuboid_extrema=cuboid)
         z0, z1 = job.in_own
         job.set_local_volume(vol[z0:z1])
         kp = job.detect()
@@ -52,22 +53,23 @@ def _worker(rank, world, port, dims, outdir):
         dist.destroy_process_group()
 
 
-def _reference(dims):
+def _reference(dims, cuboid=False):
     from oracle import sift3d_oracle as so
     nx, ny, nz = dims
     vol = so.synth_survey(dims, nblob=int(200 * nx * ny * nz / 64 ** 3))
-    o = so.Oracle()
+    o = so.Oracle(cuboid_extrema=cuboid)
     assert o.detect(vol) == 0 and o.describe() == 0
     return o
 
 
-@pytest.mark.parametrize("world,dims", [(2, (40, 44, 200)), (3, (36, 40, 152)), (2, (24, 24, 40))])
-def test_sharded_equals_single(world, dims):
+@pytest.mark.parametrize("world,dims,cuboid", [(2, (40, 44, 200), False), (3, (36, 40, 152), False),
+                                               (2, (24, 24, 40), False), (2, (40, 44, 200), True)])
+def test_sharded_equals_single(world, dims, cuboid):
     import torch.multiprocessing as mp
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), dims, d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), dims, d, cuboid), nprocs=world, join=True)
         res = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(world)]
-    o = _reference(dims)
+    o = _reference(dims, cuboid)
     ok = o.keypoints()
     assert len(ok) > 5
     want_mat = o.desc_mat()
