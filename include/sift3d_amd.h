@@ -52,6 +52,11 @@ sift3d_amd_image_set_units(sift3d_image *im, double ux, double uy, double uz);
 SIFT3D_AMD_API int
 sift3d_amd_detector_set_cuboid_extrema(sift3d_detector *det, int on);
 
+/* Dimensions (nx, ny, nz, nc) and voxel spacing of an image, e.g. one returned by
+ * sift3d_read_image (the reference keeps both private).  Either output may be NULL. */
+SIFT3D_AMD_API int
+sift3d_amd_image_info(const sift3d_image *im, int *dims4, double *units3);
+
 /* Wall-clock seconds of the stages of the last detect/describe on `det`:
  * [0] upload+scale  [1] Gaussian pyramid  [2] DoG  [3] extrema  [4] orientation
  * [5] describe  [6] pyramid kernels only, device time from HIP events

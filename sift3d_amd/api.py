@@ -10,6 +10,7 @@ Volumes are numpy float32 arrays of shape [nz, ny, nx] (x fastest), which is the
 layout of sift3d_image_data() (reference: sift3d/imutil.c:520-533).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -70,6 +71,7 @@ def lib():
         "sift3d_amd_image_set_units": (C.c_int, [vp, C.c_double, C.c_double, C.c_double]),
         "sift3d_amd_timings": (C.POINTER(C.c_double), [vp]),
         "sift3d_amd_num_candidates": (C.c_int, [vp]),
+        "sift3d_amd_image_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
         "sift3d_amd_detector_set_cuboid_extrema": (C.c_int, [vp, C.c_int]),
         "sift3d_amd_copy_level": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, _i32p]),
         "sift3d_amd_keypoint_store_size": (C.c_int, [vp]),
@@ -140,6 +142,26 @@ class Image:
         if not self.h:
             raise ValueError("sift3d_make_image(%d, %d, %d, %d) failed" % (nx, ny, nz, nc))
         self.shape = (nz, ny, nx) if nc == 1 else (nz, ny, nx, nc)
+
+    @classmethod
+    def read(cls, path):
+        """sift3d_read_image: single-file NIFTI-1 (.nii, .nii.gz).  Raises IOError on failure."""
+        h = lib().sift3d_read_image(os.fsencode(path))
+        if not h:
+            raise IOError("sift3d_read_image(%r) failed" % (path,))
+        self = cls.__new__(cls)
+        self.h = h
+        dims = (C.c_int * 4)()
+        lib().sift3d_amd_image_info(h, dims, None)
+        nx, ny, nz, nc = dims
+        self.shape = (nz, ny, nx) if nc == 1 else (nz, ny, nx, nc)
+        return self
+
+    @property
+    def units(self):
+        u = (C.c_double * 3)()
+        lib().sift3d_amd_image_info(self.h, None, u)
+        return tuple(u)
 
     @classmethod
     def from_array(cls, vol, units=None):

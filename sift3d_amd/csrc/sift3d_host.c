@@ -188,13 +188,165 @@ static const char *file_ext(const char *path)
     return (!dot || dot == name) ? "" : dot + 1;
 }
 
+/* ---- NIfTI-1 single-file reader (.nii, .nii.gz) ---------------------------------------
+ * The reference reads images through nifticlib (nifti.c:52-167); that library is not part of
+ * this build, so the subset the reference actually uses is read directly: header fields dim,
+ * datatype, pixdim, vox_offset, scl_slope, scl_inter; either byte order; the ten integer/float
+ * sample types of nifti.c:118-148; value = (float)((double)raw * slope + inter) with slope 0
+ * read as 1 (nifti.c:107-116); a 4th dimension becomes channels stored innermost
+ * (im_default_stride, nifti.c:44-46).  Analyze/NIfTI pairs (.img/.hdr) are not read. */
+static void swap_bytes(void *p, size_t size, size_t count)
+{
+    unsigned char *b = (unsigned char *)p;
+    size_t i, j;
+    for (i = 0; i < count; i++, b += size)
+        for (j = 0; j < size / 2; j++) {
+            const unsigned char t = b[j];
+            b[j] = b[size - 1 - j];
+            b[size - 1 - j] = t;
+        }
+}
+
+static double nii_sample(const unsigned char *p, int datatype)
+{
+    switch (datatype) {
+    case 2: return (double)*(const uint8_t *)p;
+    case 256: return (double)*(const int8_t *)p;
+    case 4: { int16_t v; memcpy(&v, p, 2); return (double)v; }
+    case 512: { uint16_t v; memcpy(&v, p, 2); return (double)v; }
+    case 8: { int32_t v; memcpy(&v, p, 4); return (double)v; }
+    case 768: { uint32_t v; memcpy(&v, p, 4); return (double)v; }
+    case 1024: { int64_t v; memcpy(&v, p, 8); return (double)v; }
+    case 1280: { uint64_t v; memcpy(&v, p, 8); return (double)v; }
+    case 16: { float v; memcpy(&v, p, 4); return (double)v; }
+    default: { double v; memcpy(&v, p, 8); return v; }           /* 64 */
+    }
+}
+
+static sift3d_image *read_nii(const char *path)
+{
+    unsigned char hdr[348];
+    int16_t dim[8], datatype;
+    float pixdim[8], vox_offset, slope_f, inter_f;
+    int32_t sizeof_hdr;
+    int swap, i, ndim, dim_counter, nx, ny, nz, nc, x, y, z, c;
+    size_t bytes_per, nvox, row_bytes;
+    double slope;
+    unsigned char *row = NULL;
+    sift3d_image *im = NULL;
+    gzFile f = gzopen(path, "rb");                 /* reads plain files too */
+    if (!f) {
+        ERR("read_nii: failure loading file %s", path);        /* nifti.c:63 */
+        return NULL;
+    }
+    if (gzread(f, hdr, 348) != 348)
+        goto bad_file;
+    memcpy(&sizeof_hdr, hdr, 4);
+    swap = sizeof_hdr != 348;
+    if (swap) {
+        swap_bytes(&sizeof_hdr, 4, 1);
+        if (sizeof_hdr != 348)
+            goto bad_file;
+    }
+    if (memcmp(hdr + 344, "n+1", 4)) {             /* "ni1": header/image pair */
+        ERR("read_nii: %s is not a single-file NIFTI-1 image \n", path);
+        goto fail;
+    }
+    memcpy(dim, hdr + 40, 16);
+    memcpy(&datatype, hdr + 70, 2);
+    memcpy(pixdim, hdr + 76, 32);
+    memcpy(&vox_offset, hdr + 108, 4);
+    memcpy(&slope_f, hdr + 112, 4);
+    memcpy(&inter_f, hdr + 116, 4);
+    if (swap) {
+        swap_bytes(dim, 2, 8);
+        swap_bytes(&datatype, 2, 1);
+        swap_bytes(pixdim, 4, 8);
+        swap_bytes(&vox_offset, 4, 1);
+        swap_bytes(&slope_f, 4, 1);
+        swap_bytes(&inter_f, 4, 1);
+    }
+    ndim = dim[0];
+    if (ndim < 1 || ndim > 7)
+        goto bad_file;
+    for (i = 1; i <= ndim; i++)
+        if (dim[i] < 1)
+            goto bad_file;
+    /* dimensionality = last dimension greater than 1 (nifti.c:67-72) */
+    for (dim_counter = ndim; dim_counter > 0; dim_counter--)
+        if (dim[dim_counter] > 1)
+            break;
+    if (dim_counter > 4) {
+        ERR("read_nii: file %s has unsupported dimensionality %d\n", path, dim_counter);
+        goto fail;
+    }
+    nx = dim[1];
+    ny = ndim >= 2 ? dim[2] : 1;
+    nz = ndim >= 3 ? dim[3] : 1;
+    nc = dim_counter == 4 ? dim[4] : 1;            /* nifti.c:97 */
+    switch (datatype) {
+    case 2: case 256: bytes_per = 1; break;
+    case 4: case 512: bytes_per = 2; break;
+    case 8: case 768: case 16: bytes_per = 4; break;
+    case 1024: case 1280: case 64: bytes_per = 8; break;
+    default:
+        ERR("read_nii: unsupported datatype %d \n", (int)datatype);     /* nifti.c:149-155 */
+        goto fail;
+    }
+    if (!(vox_offset >= 348.0f) || gzseek(f, (z_off_t)vox_offset, SEEK_SET) < 0)
+        goto bad_file;
+    if (!(im = sift3d_make_image(nx, ny, nz, nc)))
+        goto fail;
+    /* real world coordinates, nifti.c:87-90 (nifticlib: dx,dy,dz = pixdim[1..3]) */
+    im->ux = pixdim[1];
+    im->uy = pixdim[2];
+    im->uz = pixdim[3];
+    if (!(im->ux > 0) || !(im->uy > 0) || !(im->uz > 0)) {
+        ERR("read_nii: file %s has a non-positive voxel spacing (%f, %f, %f) \n", path, im->ux,
+            im->uy, im->uz);
+        goto fail;
+    }
+    slope = slope_f;
+    if (slope == 0.0)
+        slope = 1.0;                               /* nifti.c:107-109 */
+    nvox = (size_t)nx * ny * nz;
+    row_bytes = (size_t)nx * bytes_per;
+    if (!(row = (unsigned char *)malloc(row_bytes)))
+        goto fail;
+    for (c = 0; c < nc; c++)                       /* file order: channel slowest */
+        for (z = 0; z < nz; z++)
+            for (y = 0; y < ny; y++) {
+                if ((size_t)gzread(f, row, (unsigned)row_bytes) != row_bytes)
+                    goto bad_file;
+                if (swap)
+                    swap_bytes(row, bytes_per, (size_t)nx);
+                for (x = 0; x < nx; x++)
+                    im->data[(size_t)c + (size_t)nc * ((size_t)x + (size_t)nx * ((size_t)y + (size_t)ny * z))] =
+                        (float)(nii_sample(row + (size_t)x * bytes_per, datatype) * slope +
+                                (double)inter_f);                      /* nifti.c:112-116 */
+            }
+    (void)nvox;
+    free(row);
+    gzclose(f);
+    return im;
+bad_file:
+    ERR("read_nii: failure loading file %s", path);
+fail:
+    free(row);
+    sift3d_free_image(im);
+    gzclose(f);
+    return NULL;
+}
+
 sift3d_image *sift3d_read_image(const char *path)
 {
     const char *ext = file_ext(path);
-    if (!strcmp(ext, "img") || !strcmp(ext, "gz") || !strcmp(ext, "nii")) {
-        /* nifti.c:16-31: the wrapper is not part of this build */
-        ERR("sift3d_read_image: this build has no NIFTI support (nifticlib is not "
-            "available); fill an image made with sift3d_make_image() instead \n");
+    if (!strcmp(ext, "gz") || !strcmp(ext, "nii"))             /* im_get_format, imutil.c:318-333 */
+        return read_nii(path);
+    if (!strcmp(ext, "img")) {
+        /* Analyze pairs went through nifticlib (nifti.c:16-31: not part of this build) */
+        ERR("sift3d_read_image: Analyze (.img/.hdr) images are not supported by this build; use "
+            "single-file NIFTI (.nii, .nii.gz) or fill an image made with sift3d_make_image() \n");
     } else {
         ERR("im_read: unrecognized file extension from file %s \n", path); /* imutil.c:366 */
     }
@@ -202,6 +354,19 @@ sift3d_image *sift3d_read_image(const char *path)
 }
 
 float *sift3d_image_data(const sift3d_image *im) { return im->data; }
+
+int sift3d_amd_image_info(const sift3d_image *im, int *dims4, double *units3)
+{
+    if (!im)
+        return SIFT3D_FAILURE;
+    if (dims4) {
+        dims4[0] = im->nx; dims4[1] = im->ny; dims4[2] = im->nz; dims4[3] = im->nc;
+    }
+    if (units3) {
+        units3[0] = im->ux; units3[1] = im->uy; units3[2] = im->uz;
+    }
+    return SIFT3D_SUCCESS;
+}
 
 int sift3d_amd_image_set_units(sift3d_image *im, double ux, double uy, double uz)
 {

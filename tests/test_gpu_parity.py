@@ -436,3 +436,30 @@ def test_g5_512_golden(gpu, oracle_mod):
     exact_D = util.digest(m[:, 3:]) == dig["desc_hist"]
     # the contract is 1e-5; bit-exactness of R and of the descriptors is reported, not required
     print("g5_512: R bit-exact: %s, descriptors bit-exact: %s" % (exact_R, exact_D))
+
+
+def test_read_image_then_detect(gpu, oracle_mod, tmp_path):
+    """kpSift3D's flow (cli/kpSift3D.c:96-146): sift3d_read_image -> detect -> describe, on an
+    anisotropic int16 NIFTI file with scl_slope/scl_inter; equals the same volume passed as an
+    array with the same spacing, and the oracle."""
+    from tests.test_host_api import _write_nii
+    api, hip, torch = gpu
+    vol = oracle_mod.synth_survey((40, 33, 47))
+    raw = np.round(vol * 2000).astype(np.int16)
+    units = (1.0, 1.5, 0.7)
+    p = tmp_path / "vol.nii.gz"
+    _write_nii(p, raw, pixdim=units, slope=0.5, inter=3.0)
+    im = api.Image.read(str(p))
+    want = (raw.astype(np.float64) * 0.5 + 3.0).astype(np.float32)
+    np.testing.assert_array_equal(im.data(), want)
+    assert im.units == tuple(np.float32(u).item() for u in units)
+    det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+    assert det.detect_keypoints(im, kp) == 0 and det.extract_descriptors(kp, desc) == 0
+    o = oracle_mod.Oracle()
+    assert o.detect(want, im.units) == 0 and o.describe() == 0
+    k, ok = kp.records(), o.keypoints()
+    assert len(k) == len(ok) > 5 and det.num_candidates() == len(o.candidates())
+    for f in ("o", "s", "xd", "yd", "zd", "sd", "strength"):
+        np.testing.assert_array_equal(k[f], ok[f], err_msg=f)
+    assert util.rel_err(k["R"], ok["R"]) <= RTOL
+    assert util.rel_err(desc.to_mat_rm(), o.desc_mat()) <= RTOL

@@ -161,3 +161,102 @@ def test_synth_generators_match_oracle_build(api, oracle_mod):
     np.testing.assert_array_equal(api.synth_survey(24), oracle_mod.synth_survey(24))
     np.testing.assert_array_equal(api.synth_lattice((20, 12, 9), seed=5),
                                   oracle_mod.synth_lattice((20, 12, 9), seed=5))
+
+
+# ----------------------------------------------------------------------------------------
+# sift3d_read_image: single-file NIFTI-1 (the reference reads through nifticlib,
+# nifti.c:52-167; no reference build with nifticlib exists here, so these tests pin the reader
+# against files written from the NIFTI-1 specification)
+# ----------------------------------------------------------------------------------------
+_NII_TYPES = {np.dtype("u1"): 2, np.dtype("i1"): 256, np.dtype("i2"): 4, np.dtype("u2"): 512,
+              np.dtype("i4"): 8, np.dtype("u4"): 768, np.dtype("i8"): 1024, np.dtype("u8"): 1280,
+              np.dtype("f4"): 16, np.dtype("f8"): 64}
+
+
+def _write_nii(path, arr, pixdim=(1.0, 1.0, 1.0), slope=0.0, inter=0.0, big_endian=False,
+               magic=b"n+1\0", vox_offset=352):
+    """arr: [nz, ny, nx] or [nt, nz, ny, nx] (file order: x fastest)."""
+    import gzip
+    import struct
+    e = ">" if big_endian else "<"
+    dims = list(arr.shape[::-1])
+    dim = [len(dims)] + dims + [1] * (7 - len(dims))
+    hdr = bytearray(348)
+    struct.pack_into(e + "i", hdr, 0, 348)
+    struct.pack_into(e + "8h", hdr, 40, *dim)
+    struct.pack_into(e + "h", hdr, 70, _NII_TYPES[arr.dtype])
+    struct.pack_into(e + "h", hdr, 72, arr.dtype.itemsize * 8)
+    struct.pack_into(e + "8f", hdr, 76, 1.0, *pixdim, 1.0, 1.0, 1.0, 1.0)
+    struct.pack_into(e + "f", hdr, 108, float(vox_offset))
+    struct.pack_into(e + "f", hdr, 112, slope)
+    struct.pack_into(e + "f", hdr, 116, inter)
+    hdr[344:348] = magic
+    body = bytes(hdr) + b"\0" * (vox_offset - 348) + arr.astype(arr.dtype.newbyteorder(e)).tobytes()
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "wb") as f:
+        f.write(body)
+
+
+@pytest.mark.parametrize("dtype", ["u1", "i1", "i2", "u2", "i4", "u4", "i8", "u8", "f4", "f8"])
+def test_read_image_nifti_types(api, tmp_path, dtype):
+    rng = np.random.default_rng(5)
+    dt = np.dtype(dtype)
+    if dt.kind == "f":
+        a = rng.standard_normal((5, 6, 7)).astype(dt)
+    else:
+        info = np.iinfo(dt)
+        a = rng.integers(max(info.min, -10 ** 6), min(info.max, 10 ** 6), (5, 6, 7)).astype(dt)
+    p = tmp_path / ("t_%s.nii" % dtype)
+    _write_nii(p, a, pixdim=(0.5, 1.25, 3.0), slope=2.5, inter=-1.0)
+    im = api.Image.read(str(p))
+    assert im.shape == (5, 6, 7) and im.units == (0.5, 1.25, 3.0)
+    want = (a.astype(np.float64) * 2.5 + (-1.0)).astype(np.float32)   # nifti.c:112-116
+    np.testing.assert_array_equal(im.data(), want)
+
+
+def test_read_image_nifti_variants(api, tmp_path):
+    rng = np.random.default_rng(6)
+    a = rng.standard_normal((4, 5, 9)).astype(np.float32)
+    # gzip, big-endian, slope 0 = identity, data not directly after the header
+    p = tmp_path / "v.nii.gz"
+    _write_nii(p, a, big_endian=True, vox_offset=400)
+    im = api.Image.read(str(p))
+    np.testing.assert_array_equal(im.data(), a)
+    assert im.units == (1.0, 1.0, 1.0)
+    # a 4th dimension becomes channels, stored innermost (nifti.c:44-46,97)
+    b = rng.integers(0, 100, (3, 4, 5, 6)).astype(np.int16)
+    p = tmp_path / "c.nii"
+    _write_nii(p, b)
+    im = api.Image.read(str(p))
+    assert im.shape == (4, 5, 6, 3)
+    np.testing.assert_array_equal(im.data(), np.moveaxis(b, 0, -1).astype(np.float32))
+    # trailing singleton dimensions are ignored; a real 5th dimension is refused (nifti.c:76-80)
+    p = tmp_path / "s.nii"
+    _write_nii(p, a[None, None])
+    assert api.Image.read(str(p)).shape == (4, 5, 9)
+    p = tmp_path / "5d.nii"
+    _write_nii(p, np.zeros((2, 1, 3, 3, 3), np.float32))
+    with pytest.raises(IOError):
+        api.Image.read(str(p))
+    # header/image pairs, truncated files, unknown sample types, wrong extension
+    p = tmp_path / "pair.nii"
+    _write_nii(p, a, magic=b"ni1\0")
+    with pytest.raises(IOError):
+        api.Image.read(str(p))
+    p = tmp_path / "trunc.nii"
+    _write_nii(p, a)
+    raw = open(p, "rb").read()
+    open(p, "wb").write(raw[:-10])
+    with pytest.raises(IOError):
+        api.Image.read(str(p))
+    p = tmp_path / "cplx.nii"
+    _write_nii(p, a)
+    raw = bytearray(open(p, "rb").read())
+    raw[70:72] = (32).to_bytes(2, "little")                 # NIFTI_TYPE_COMPLEX64
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(IOError):
+        api.Image.read(str(p))
+    with pytest.raises(IOError):
+        api.Image.read(str(tmp_path / "missing.nii"))
+    with pytest.raises(IOError):
+        api.Image.read(str(tmp_path / "x.img"))
