@@ -260,6 +260,9 @@ typedef struct {
     float R[9];
     float cx, cy, cz; /* (float) keypoint voxel coordinates in its level, global z */
     int32_t level;
+    uint32_t row1;    /* 0: the histogram goes to row i of d_hist (i = position in d_kp);
+                       * r + 1: to row r -- lets the caller launch the widest windows first
+                       * (longest-job-first keeps the kernel's tail short) */
     double sd;
 } sift3d_hip_kp;
 

@@ -1467,15 +1467,27 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
             return SIFT3D_FAILURE;
         d->kp_cap = cap;
     }
-    for (i = 0; i < num; i++) {
-        const keypoint_t *k = kp->buf + i;
-        sift3d_hip_kp *q = d->h_kp + i;
-        memcpy(q->R, k->R, sizeof(q->R));
-        q->cx = (float)k->xd;                          /* sift.c:1474-1476 */
-        q->cy = (float)k->yd;
-        q->cz = (float)k->zd;
-        q->level = k->o * d->ngl + k->s + 1;
-        q->sd = k->sd;
+    {
+        /* Launch order: widest windows first.  The window radius in level voxels grows with
+         * the level index s only (14.14 * sigma0 * 2^(s/K)), and a keypoint of the last level
+         * costs ~4x one of the first; longest-job-first keeps the tail of the one-wave-per-
+         * keypoint kernel short.  row1 sends every histogram to its keypoint's row. */
+        int sv, pos = 0;
+        for (sv = d->ngl - 2; sv >= -1; sv--)
+            for (i = 0; i < num; i++) {
+                const keypoint_t *k = kp->buf + i;
+                sift3d_hip_kp *q;
+                if (k->s != sv)
+                    continue;
+                q = d->h_kp + pos++;
+                memcpy(q->R, k->R, sizeof(q->R));
+                q->cx = (float)k->xd;                  /* sift.c:1474-1476 */
+                q->cy = (float)k->yd;
+                q->cz = (float)k->zd;
+                q->level = k->o * d->ngl + k->s + 1;
+                q->row1 = (uint32_t)i + 1u;
+                q->sd = k->sd;
+            }
     }
     /* do_extract_descriptors, sift.c:1561-1596 */
     desc->nx = d->odims[0][0];

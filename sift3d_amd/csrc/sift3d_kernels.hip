@@ -1178,6 +1178,7 @@ __device__ __forceinline__ bool cuboid_extremum(const float *__restrict__ prev,
     return gt || lt;
 }
 
+template <bool CUBOID>
 __global__ __launch_bounds__(256) void k_extrema_mask(ExLevels LV, ExGeom E,
                                                       unsigned long long *__restrict__ masks,
                                                       uint32_t *__restrict__ blk_counts)
@@ -1221,7 +1222,7 @@ __global__ __launch_bounds__(256) void k_extrema_mask(ExLevels LV, ExGeom E,
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 bool hit = false;
-                if (E.cuboid) {
+                if (CUBOID) {
                     if (ok[k] && (v[k] > thr || v[k] < -thr))            // sift.c:842
                         hit = cuboid_extremum(L.prev, L.cur, L.next, p[k], ys, zs, v[k]);
                 } else if (ok[k] && (v[k] > thr || v[k] < -thr)) {       // sift.c:842
@@ -1387,9 +1388,11 @@ __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restric
     // rows padded by 16 bytes: the accumulator lanes' 16-byte reads fall on different banks
     __shared__ __attribute__((aligned(16))) double td[6][66];
     __shared__ __attribute__((aligned(16))) float tf[3][68];
-    const uint32_t ci = blockIdx.x;
-    if (ci >= n)
+    if (blockIdx.x >= n)
         return;
+    // candidates arrive in (o, s, z, y, x) order and the window grows with s: walking the list
+    // backwards starts the widest windows first (longest-job-first, short kernel tail)
+    const uint32_t ci = n - 1 - blockIdx.x;
     const int lane = threadIdx.x;
     const sift3d_hip_cand C = cand[ci];
     const sift3d_hip_level L = levels[C.tag];
@@ -1599,6 +1602,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const int lane = threadIdx.x;
     const sift3d_hip_kp K = kps[ki];
     const sift3d_hip_level L = levels[K.level];
+    const uint32_t orow = K.row1 ? K.row1 - 1 : ki;   // output row (launch order may differ)
     for (int i = lane; i < HIST_LDS; i += 64)
         hist[i] = 0.0f;
     if (lane < 12) {
@@ -1962,7 +1966,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         __syncthreads();
     }
     for (int i = lane; i < 768; i += 64)
-        out[(size_t)ki * 768 + i] = hist[c_bin_off[i % 12] + i / 12];
+        out[(size_t)orow * 768 + i] = hist[c_bin_off[i % 12] + i / 12];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2485,7 +2489,12 @@ int sift3d_hip_extrema_mode(const sift3d_hip_extrema_level *levels, int nlevels,
         LV.lv[i] = levels[i];
     unsigned long long *masks = reinterpret_cast<unsigned long long *>(d_work);
     uint32_t *blk = reinterpret_cast<uint32_t *>(masks + (size_t)nlevels * E.nwords);
-    hipLaunchKernelGGL(k_extrema_mask, dim3(E.nblk, nlevels), dim3(256), 0, st, LV, E, masks, blk);
+    if (E.cuboid)
+        hipLaunchKernelGGL(k_extrema_mask<true>, dim3(E.nblk, nlevels), dim3(256), 0, st, LV, E, masks,
+                           blk);
+    else
+        hipLaunchKernelGGL(k_extrema_mask<false>, dim3(E.nblk, nlevels), dim3(256), 0, st, LV, E, masks,
+                           blk);
     hipLaunchKernelGGL(k_extrema_scan, dim3(1), dim3(1024), 0, st, blk, E.nblk * (uint32_t)nlevels,
                        d_count);
     hipLaunchKernelGGL(k_extrema_emit, dim3(E.nblk, nlevels), dim3(256), 0, st, LV, E, masks, blk,

@@ -34,7 +34,7 @@ class Level(C.Structure):
 
 CAND_DTYPE = np.dtype([("idx", "u4"), ("tag", "i4"), ("val", "f4")])
 KP_DTYPE = np.dtype([("R", "f4", (9,)), ("cx", "f4"), ("cy", "f4"), ("cz", "f4"),
-                     ("level", "i4"), ("sd", "f8")], align=True)
+                     ("level", "i4"), ("row1", "u4"), ("sd", "f8")], align=True)
 LEVEL_DTYPE = np.dtype([("data", "u8"), ("nx", "i4"), ("ny", "i4"), ("nz", "i4"),
                         ("z_off", "i4"), ("nz_glob", "i4"), ("ux", "f4"), ("uy", "f4"),
                         ("uz", "f4"), ("octave", "i4"), ("sd", "f8")], align=True)

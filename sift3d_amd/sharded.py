@@ -637,9 +637,13 @@ class ShardedSift3D:
         idx = np.nonzero(mine)[0]
         q = np.zeros(len(idx), HKP)
         k = kp[idx]
+        # launch order: widest windows (largest s) first, each histogram to its own row
+        order = np.argsort(-k["s"].astype(np.int64), kind="stable")
+        k = k[order]
         q["R"] = k["R"].reshape(-1, 9)
         q["cx"], q["cy"], q["cz"] = k["xd"], k["yd"], k["zd"]
         q["level"] = k["o"] * g.ngl + k["s"] + 1
+        q["row1"] = order + 1
         q["sd"] = k["sd"]
         self.my_kp_idx = idx
         self.my_desc = be.describe(self._table, q)

@@ -140,7 +140,8 @@ class OracleBackend:
             d = so.Descriptor()
             self.L.orc_describe_slab(t.data_ptr(), nx, ny, nzl, L["off"], L["nz_glob"],
                                      np.array(L["units"], np.float64), C.byref(key), C.byref(d))
-            out[i] = np.ctypeslib.as_array(d.hist)
+            row = int(k["row1"]) - 1 if int(k["row1"]) else i   # as the HIP kernel
+            out[row] = np.ctypeslib.as_array(d.hist)
         return out
 
     def synth(self, t, z_off, seed):
