@@ -942,10 +942,28 @@ __global__ __launch_bounds__(256) void k_fir_x_dy(FirParams P, FirTaps T)
     __shared__ __attribute__((aligned(16))) float lds[4][L];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nrows = P.ny * (P.z_hi - P.z_lo);
+    const int nx = P.nx;
+    const int nmain = (nrows + 3) / 4;             // blockIdx.y >= nmain: boundary-column blocks
+    if ((int)blockIdx.y >= nmain) {
+        // The uhw low and uhw + 1 high columns of every row take the reference's boundary
+        // path (imutil.c:829-850): one thread per such output, the literal arithmetic.  They
+        // ride in the same launch; the interior blocks below do not store those columns.
+        const int nedge = 2 * P.uhw + 1;
+        const size_t i = ((size_t)(blockIdx.y - nmain) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        if (i >= (size_t)nrows * nedge)
+            return;
+        const size_t erow = i / nedge;
+        const int e = (int)(i % nedge);
+        const int x = e < P.uhw ? e : nx - 1 - P.uhw + (e - P.uhw);
+        if (x < 0 || x >= nx || (x >= P.uhw && x <= nx - 2 - P.uhw))
+            return;
+        const size_t eoff = ((size_t)P.z_lo * P.ny + erow) * nx;
+        P.dst[eoff + x] = fir_literal_t<HW>(P.src + eoff, 1, x, nx, 0, nx, T.k, P.hw, P.uf, P.uhw);
+        return;
+    }
     const int row = blockIdx.y * 4 + wave;
     const bool active = row < nrows;
     const int x0 = blockIdx.x * SEG;
-    const int nx = P.nx;
     const size_t rowoff = active ? ((size_t)(P.z_lo + row / P.ny) * P.ny + (row % P.ny)) * nx : 0;
     const float *__restrict__ s = P.src + rowoff;
     float *__restrict__ d = P.dst + rowoff;
@@ -986,9 +1004,16 @@ __global__ __launch_bounds__(256) void k_fir_x_dy(FirParams P, FirTaps T)
             const int of = ((-dd) >> S);
             dy_term<S, 1>(acc, T.k[dd + HW], dd, w[HALO + r + of], w[HALO + r + of + 1]);
         }
-        o[r] = acc;   // boundary columns are rewritten by k_fir_x_edges
+        o[r] = acc;
     }
-    if (vec_ok && xb + RX <= nx) {
+    // boundary columns belong to the edge blocks of this launch
+    const bool has_edge = xb < P.uhw || xb + RX - 1 > nx - 2 - P.uhw;
+    if (has_edge) {
+#pragma unroll
+        for (int r = 0; r < RX; r++)
+            if (xb + r < nx && xb + r >= P.uhw && xb + r <= nx - 2 - P.uhw)
+                d[xb + r] = o[r];
+    } else if (vec_ok && xb + RX <= nx) {
         st4(d + xb, make_float4(o[0], o[1], o[2], o[3]));
         st4(d + xb + 4, make_float4(o[4], o[5], o[6], o[7]));
     } else {
@@ -997,24 +1022,6 @@ __global__ __launch_bounds__(256) void k_fir_x_dy(FirParams P, FirTaps T)
             if (xb + r < nx)
                 d[xb + r] = o[r];
     }
-}
-
-// boundary columns of an x pass (x < uhw or x > nx-2-uhw): one thread per (row, column)
-template <int HW>
-__global__ __launch_bounds__(256) void k_fir_x_edges(FirParams P, FirTaps T)
-{
-    const int nedge = 2 * P.uhw + 1;               // uhw low + (uhw + 1) high columns
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nrows = (size_t)P.ny * (P.z_hi - P.z_lo);
-    if (i >= nrows * nedge)
-        return;
-    const size_t row = i / nedge;
-    const int e = (int)(i % nedge);
-    const int x = e < P.uhw ? e : P.nx - 1 - P.uhw + (e - P.uhw);
-    if (x < 0 || x >= P.nx || (x >= P.uhw && x <= P.nx - 2 - P.uhw))
-        return;
-    const size_t rowoff = ((size_t)P.z_lo * P.ny + row) * P.nx;
-    P.dst[rowoff + x] = fir_literal_t<HW>(P.src + rowoff, 1, x, P.nx, 0, P.nx, T.k, P.hw, P.uf, P.uhw);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2110,10 +2117,11 @@ static void launch_fir_dy(const FirParams &P, const SweepGeom &G, const FirTaps 
 {
     if (P.axis == 0) {
         const int nrows = P.ny * (P.z_hi - P.z_lo);
-        dim3 grid((P.nx + 511) / 512, (nrows + 3) / 4);
-        hipLaunchKernelGGL((k_fir_x_dy<HW, S>), grid, dim3(256), 0, st, P, T);
+        const unsigned gx = (P.nx + 511) / 512;
         const size_t nedge = (size_t)nrows * (2 * P.uhw + 1);
-        hipLaunchKernelGGL(k_fir_x_edges<HW>, dim3((unsigned)((nedge + 255) / 256)), dim3(256), 0, st, P, T);
+        const unsigned eblocks = (unsigned)((nedge + (size_t)256 * gx - 1) / ((size_t)256 * gx));
+        dim3 grid(gx, (nrows + 3) / 4 + eblocks);   // interior blocks, then boundary-column blocks
+        hipLaunchKernelGGL((k_fir_x_dy<HW, S>), grid, dim3(256), 0, st, P, T);
     } else {
         const int nseg = (G.out_hi - G.out_lo + P.ts - 1) / P.ts;
         dim3 grid((G.ncols + 255) / 256, nseg);
