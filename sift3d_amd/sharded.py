@@ -142,7 +142,9 @@ class HipBackend:
     def extrema_orient(self, specs, table, peak, corner, cuboid=False):
         """detect_extrema for every octave (one shared candidate buffer, device-side running
         count, a single host sync) followed by assign_orientations on the device-resident
-        candidates.  specs: [(levels, nx, ny, nz_local)].  Returns host arrays (cands, R, keep)."""
+        candidates; the oriented ones are compacted on the device.  specs: [(levels, nx, ny,
+        nz_local)].  Returns host arrays: tag and |DoG| value of EVERY candidate (scan order),
+        and for the kept ones their position in that list, voxel index and R."""
         torch, hip = self.torch, self.hip
         L = hip.lib()
         wb = max(L.sift3d_hip_extrema_work_bytes(nx, ny, nz, len(lv)) for lv, nx, ny, nz in specs)
@@ -156,10 +158,11 @@ class HipBackend:
                 self._cand = torch.empty(self._cap * 12, dtype=torch.uint8, device="cuda")
                 self._R = torch.empty((self._cap, 9), dtype=torch.float32, device="cuda")
                 self._keep = torch.empty(self._cap, dtype=torch.int32, device="cuda")
-                # page-locked mirrors: the three read-backs run as plain DMA, one sync
-                self._cand_h = torch.empty(self._cap * 12, dtype=torch.uint8, pin_memory=True)
-                self._R_h = torch.empty((self._cap, 9), dtype=torch.float32, pin_memory=True)
-                self._keep_h = torch.empty(self._cap, dtype=torch.int32, pin_memory=True)
+                # page-locked mirrors: the read-backs run as plain DMA, one sync
+                pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)  # noqa: E731
+                self._host = dict(tag=pin(self._cap, torch.int32), val=pin(self._cap, torch.int32),
+                                  pos=pin(self._cap, torch.int64), idx=pin(self._cap, torch.int32),
+                                  R=pin((self._cap, 9), torch.float32))
             self._count.zero_()
             for lv, nx, ny, nz in specs:
                 arr = (hip.ExtremaLevel * len(lv))()
@@ -178,16 +181,23 @@ class HipBackend:
                 break
             self._cap = n + n // 4 + 1024
         if n == 0:
-            return (np.zeros(0, hip.CAND_DTYPE), np.zeros((0, 9), np.float32), np.zeros(0, np.int32))
+            return (np.zeros(0, np.int32), np.zeros(0, np.float32), np.zeros(0, np.int64),
+                    np.zeros(0, np.uint32), np.zeros((0, 9), np.float32))
         hip._check(L.sift3d_hip_orient(table.data_ptr(), self._cand.data_ptr(), n, float(corner),
                                        self._R.data_ptr(), self._keep.data_ptr(),
                                        hip.current_stream()), "sift3d_hip_orient")
-        self._cand_h[:n * 12].copy_(self._cand[:n * 12], non_blocking=True)
-        self._R_h[:n].copy_(self._R[:n], non_blocking=True)
-        self._keep_h[:n].copy_(self._keep[:n], non_blocking=True)
+        rec = self._cand[:n * 12].view(torch.int32).view(n, 3)     # idx, tag, val (sift3d_hip_cand)
+        kept = torch.nonzero(self._keep[:n]).squeeze(1)             # ascending = scan order
+        nk = int(kept.numel())
+        h = self._host
+        h["tag"][:n].copy_(rec[:, 1], non_blocking=True)
+        h["val"][:n].copy_(rec[:, 2], non_blocking=True)
+        h["pos"][:nk].copy_(kept, non_blocking=True)
+        h["idx"][:nk].copy_(rec[kept, 0], non_blocking=True)
+        h["R"][:nk].copy_(self._R[kept], non_blocking=True)
         torch.cuda.synchronize()
-        return (self._cand_h[:n * 12].numpy().view(hip.CAND_DTYPE), self._R_h[:n].numpy(),
-                self._keep_h[:n].numpy())
+        return (h["tag"][:n].numpy(), h["val"][:n].numpy().view(np.float32), h["pos"][:nk].numpy(),
+                h["idx"][:nk].numpy().view(np.uint32), h["R"][:nk].numpy())
 
     def describe(self, table, kps):
         torch, hip = self.torch, self.hip
@@ -202,7 +212,13 @@ class HipBackend:
             if not self._hist_dev:
                 raise RuntimeError("pinned descriptor buffer is not visible to the device: %s"
                                    % hip.lib().sift3d_hip_last_error().decode())
-        dk = torch.from_numpy(np.ascontiguousarray(kps).view(np.uint8)).cuda()
+        nb = n * kps.dtype.itemsize
+        if getattr(self, "_kp_host", None) is None or self._kp_host.numel() < nb:
+            self._kp_host = torch.empty(nb + nb // 8, dtype=torch.uint8, pin_memory=True)
+            self._kp_dev = torch.empty(nb + nb // 8, dtype=torch.uint8, device="cuda")
+        self._kp_host[:nb].numpy()[:] = np.ascontiguousarray(kps).view(np.uint8).reshape(-1)
+        self._kp_dev[:nb].copy_(self._kp_host[:nb], non_blocking=True)
+        dk = self._kp_dev
         hip._check(hip.lib().sift3d_hip_describe(table.data_ptr(), dk.data_ptr(), n,
                                                  self._hist_dev, hip.current_stream()),
                    "sift3d_hip_describe")
@@ -567,29 +583,29 @@ class ShardedSift3D:
                                              units=self._lunits(o), octave=o,
                                              sd=self._scale(o, s - 1)))
             self._table = be.level_table(table_levels)
-        local, R, keep = be.extrema_orient(specs, self._table, self.peak, self.corner, self.cuboid)
+        tag, val, kpos, kidx, R = be.extrema_orient(specs, self._table, self.peak, self.corner,
+                                                    self.cuboid)
         # Exchange (all-gather-v): per-(o,s) counts, the candidates' |DoG| values and
         # the ORIENTED keypoints only -- the rejected candidates' records stay on their rank.
         nkey = g.num_octaves * g.K
-        tag = local["tag"].astype(np.int64)
-        oct_ = tag // g.ngl
-        key = oct_ * g.K + (tag % g.ngl - 1)        # non-decreasing: extrema emit in (o, s) order
-        km = keep != 0
-        cnt = np.stack([np.bincount(key, minlength=nkey), np.bincount(key[km], minlength=nkey)], 1)
-        lk, ok_ = local[km], oct_[km]
+        tag = tag.astype(np.int64)
+        key = (tag // g.ngl) * g.K + (tag % g.ngl - 1)   # non-decreasing: extrema emit in (o, s) order
+        ktag = tag[kpos]
+        ok_ = ktag // g.ngl
+        cnt = np.stack([np.bincount(key, minlength=nkey), np.bincount(key[kpos], minlength=nkey)], 1)
         dims = np.array(g.dims, np.int64)
         offs = np.array([self.D[o][0].off for o in range(g.num_octaves)], np.int64)
-        idx = lk["idx"].astype(np.int64)
+        idx = kidx.astype(np.int64)
         nxv, nyv = dims[ok_, 0], dims[ok_, 1]
-        rec = np.zeros(len(lk), GKP_DTYPE)
+        rec = np.zeros(len(kpos), GKP_DTYPE)
         rec["o"] = ok_
-        rec["s"] = lk["tag"] % g.ngl - 1
+        rec["s"] = ktag % g.ngl - 1
         rec["x"] = idx % nxv
         rec["y"] = (idx // nxv) % nyv
         rec["z"] = idx // (nxv * nyv) + offs[ok_]
-        rec["R"] = R[km]
+        rec["R"] = R
         cnts = self._allgather_fixed(cnt.astype(np.int64))          # [world, nkey, 2]
-        vals = self._allgather_padded(np.ascontiguousarray(local["val"]), cnts[:, :, 0].sum(1))
+        vals = self._allgather_padded(np.ascontiguousarray(val), cnts[:, :, 0].sum(1))
         recs = self._allgather_padded(rec, cnts[:, :, 1].sum(1))
         # global order: (o, s) major, then ranks in slab order (their z ranges are disjoint and
         # ascending), each rank's list already in (z, y, x) order
@@ -610,7 +626,7 @@ class ShardedSift3D:
                     got += len(c)
             val_head = np.concatenate(chunks)[:need] if chunks else np.zeros(0, np.float32)
         else:
-            kept, val_head = rec, local["val"][:len(rec)]
+            kept, val_head = rec, val[:len(rec)]
         self.ncand = int(cnts[:, :, 0].sum())
         kp = np.zeros(len(kept), KP_DTYPE)
         kp["o"], kp["s"] = kept["o"], kept["s"]
@@ -630,21 +646,23 @@ class ShardedSift3D:
         g, be, r = self.g, self.be, self.rank
         kp = self.kp if kp is None else kp
         from .hip import KP_DTYPE as HKP
-        mine = np.zeros(len(kp), bool)
-        for o in range(g.num_octaves):
-            z0, z1 = g.own(o, r)
-            mine |= (kp["o"] == o) & (kp["zd"] >= z0) & (kp["zd"] < z1)
-        idx = np.nonzero(mine)[0]
-        q = np.zeros(len(idx), HKP)
-        k = kp[idx]
+        if self.world == 1:
+            idx = np.arange(len(kp))
+        else:
+            z0s = np.array([g.own(o, r)[0] for o in range(g.num_octaves)], np.float64)
+            z1s = np.array([g.own(o, r)[1] for o in range(g.num_octaves)], np.float64)
+            ko = kp["o"]
+            idx = np.nonzero((kp["zd"] >= z0s[ko]) & (kp["zd"] < z1s[ko]))[0]
         # launch order: widest windows (largest s) first, each histogram to its own row
-        order = np.argsort(-k["s"].astype(np.int64), kind="stable")
-        k = k[order]
-        q["R"] = k["R"].reshape(-1, 9)
-        q["cx"], q["cy"], q["cz"] = k["xd"], k["yd"], k["zd"]
-        q["level"] = k["o"] * g.ngl + k["s"] + 1
+        ks = kp["s"][idx]
+        order = np.argsort(-ks.astype(np.int64), kind="stable")
+        sel = idx[order]
+        q = np.zeros(len(idx), HKP)
+        q["R"] = kp["R"][sel].reshape(-1, 9)
+        q["cx"], q["cy"], q["cz"] = kp["xd"][sel], kp["yd"][sel], kp["zd"][sel]
+        q["level"] = kp["o"][sel] * g.ngl + ks[order] + 1
         q["row1"] = order + 1
-        q["sd"] = k["sd"]
+        q["sd"] = kp["sd"][sel]
         self.my_kp_idx = idx
         self.my_desc = be.describe(self._table, q)
         return idx, self.my_desc

@@ -106,7 +106,9 @@ class OracleBackend:
         recs = [self.extrema(lv, nx, ny, nz, peak, cuboid) for lv, nx, ny, nz in specs]
         local = np.concatenate(recs) if recs else np.zeros(0, CAND_DTYPE)
         R, keep = self.orient(table, local, corner)
-        return local, R, keep
+        kpos = np.nonzero(keep)[0].astype(np.int64)
+        return (local["tag"].astype(np.int32), np.ascontiguousarray(local["val"]), kpos,
+                local["idx"][kpos].astype(np.uint32), R[kpos])
 
     def orient(self, table, cands, corner):
         n = len(cands)
