@@ -40,7 +40,7 @@ def parse(fetch_dir, write_dir, n=512):
     of the bytes of a wide coalesced streaming read, so it is doubled (MI355X_MICROARCH.md, HBM)."""
     def load(d, name):
         out = {}
-        for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] != name:
                     continue
