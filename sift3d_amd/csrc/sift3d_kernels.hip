@@ -216,6 +216,14 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return v;
+}
+
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
@@ -1257,6 +1265,142 @@ __global__ __launch_bounds__(256) void k_extrema_mask(ExLevels LV, ExGeom E,
     __syncthreads();
     if (threadIdx.x == 0)
         blk_counts[(size_t)level * E.nblk + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+// ---- three keypoint levels in one z sweep (default 8-neighbour test) -----------------------
+// The three keypoint levels of an octave share their DoG levels (next of level i = centre of
+// level i+1), and the scattered neighbour lines of k_extrema_mask cost ~4x the centre samples.
+// Here a workgroup owns a 64(x) x 16(y) column and walks z: every thread keeps three planes
+// (z-1, z, z+1) of the three centre levels in registers, so each of the five DoG levels is read
+// once along z; the y neighbours are two more (cache-resident) row loads, the x neighbours come
+// from the adjacent lanes (DPP row shift; one scalar load at the tile's ends).  Output: the same
+// 64-voxel mask words as k_extrema_mask, assembled with a DPP OR-reduction over the 16 lanes of
+// a row, so the scan and emit kernels (and with them the reference's scan order) are unchanged.
+struct ExSweep {
+    const float *d[5];        // DoG levels s-1 .. s+3 of the three keypoint levels
+    const float *absmax[3];
+    double peak_thresh;
+    int nx, ny, nz;           // local dims
+    int z_lo, z_hi, ts;       // output planes [z_lo, z_hi), segment length
+    int wpr;
+    uint32_t nwords;
+    uint32_t *masks32;        // [3][nwords] 64-bit words as uint32 pairs
+};
+
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);   // out-of-row lanes read 0
+}
+
+__global__ __launch_bounds__(256) void k_extrema_sweep3(ExSweep S)
+{
+    constexpr int TY = 16;
+    const int qx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = (blockIdx.x * 16 + qx) * 4, y = blockIdx.y * TY + ty;
+    const int nx = S.nx, ny = S.ny;
+    const size_t ys = nx, zs = (size_t)nx * ny;
+    const bool col = x < nx && y < ny;                 // (nx % 4 == 0: whole quads)
+    const int yc = min(y, ny - 1), xc = min(x, nx - 4);
+    const int yu = max(yc - 1, 0), yd = min(yc + 1, ny - 1);
+    const size_t oc = (size_t)yc * ys + xc, ou = (size_t)yu * ys + xc, od = (size_t)yd * ys + xc;
+    const int p0 = S.z_lo + blockIdx.z * S.ts, p1 = min(p0 + S.ts, S.z_hi);
+    if (p0 >= p1)
+        return;
+    float thr[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        thr[i] = (float)(S.peak_thresh * (double)(*S.absmax[i]));        // sift.c:829
+    // which of the quad's four voxels may be extrema at all (sift.c:833-838: 1 .. n-2)
+    bool okx[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+        okx[e] = col && y >= 1 && y <= ny - 2 && x + e >= 1 && x + e <= nx - 2;
+    float4 m[3], c[3], p[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        m[i] = ld4(S.d[i + 1] + (size_t)(p0 - 1) * zs + oc);
+        c[i] = ld4(S.d[i + 1] + (size_t)p0 * zs + oc);
+    }
+#pragma unroll 1
+    for (int z = p0; z < p1; z++) {
+        const size_t zo = (size_t)z * zs;
+        float4 up[3], dn[3];
+        float lf[3], rt[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float *lv = S.d[i + 1];
+            p[i] = ld4(lv + zo + zs + oc);
+            up[i] = ld4(lv + zo + ou);
+            dn[i] = ld4(lv + zo + od);
+            // x neighbours of the quad's ends: adjacent lanes of the 16-lane row, or memory at
+            // the ends of the 64-voxel tile
+            lf[i] = __int_as_float(dpp_i<0x111>(__float_as_int(c[i].w)));   // row_shr:1
+            rt[i] = __int_as_float(dpp_i<0x101>(__float_as_int(c[i].x)));   // row_shl:1
+            if (qx == 0 && col && x > 0)
+                lf[i] = lv[zo + oc - 1];
+            if (qx == 15 && col && x + 4 < nx)
+                rt[i] = lv[zo + oc + 4];
+        }
+        const float4 d0c = ld4(S.d[0] + zo + oc), d4c = ld4(S.d[4] + zo + oc);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float4 pv = i == 0 ? d0c : c[i - 1], nv = i == 2 ? d4c : c[i + 1];
+            const float cv[4] = { c[i].x, c[i].y, c[i].z, c[i].w };
+            const float pr[4] = { pv.x, pv.y, pv.z, pv.w }, ne[4] = { nv.x, nv.y, nv.z, nv.w };
+            const float uu[4] = { up[i].x, up[i].y, up[i].z, up[i].w };
+            const float dd[4] = { dn[i].x, dn[i].y, dn[i].z, dn[i].w };
+            const float zm[4] = { m[i].x, m[i].y, m[i].z, m[i].w };
+            const float zp[4] = { p[i].x, p[i].y, p[i].z, p[i].w };
+            int nib = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float v = cv[e];
+                const float xm = e > 0 ? cv[e - 1] : lf[i], xp = e < 3 ? cv[e + 1] : rt[i];
+                const bool hit =
+                    okx[e] && (v > thr[i] || v < -thr[i]) &&                           // sift.c:842
+                    ((v > pr[e] && v > xp && v > xm && v > dd[e] && v > uu[e] && v > zm[e] &&
+                      v > zp[e] && v > ne[e]) ||
+                     (v < pr[e] && v < xp && v < xm && v < dd[e] && v < uu[e] && v < zm[e] &&
+                      v < zp[e] && v < ne[e]));                                        // sift.c:844-849
+                nib |= hit ? (1 << e) : 0;
+            }
+            // 64-bit word of the row: voxel 4*qx + e -> bit 4*qx + e; OR over the 16 lanes
+            int lo = qx < 8 ? nib << (4 * qx) : 0, hi = qx >= 8 ? nib << (4 * (qx - 8)) : 0;
+            lo |= dpp_i<0x111>(lo); hi |= dpp_i<0x111>(hi);
+            lo |= dpp_i<0x112>(lo); hi |= dpp_i<0x112>(hi);
+            lo |= dpp_i<0x114>(lo); hi |= dpp_i<0x114>(hi);
+            lo |= dpp_i<0x118>(lo); hi |= dpp_i<0x118>(hi);
+            if (qx == 15 && y < ny) {
+                const size_t w = (size_t)i * S.nwords + ((size_t)z * ny + y) * S.wpr + blockIdx.x;
+                *reinterpret_cast<uint2 *>(S.masks32 + 2 * w) = make_uint2((unsigned)lo, (unsigned)hi);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            m[i] = c[i];
+            c[i] = p[i];
+        }
+    }
+}
+
+// candidates per block of EX_WPB mask words (what k_extrema_mask counts itself)
+__global__ __launch_bounds__(256) void k_extrema_count(const unsigned long long *__restrict__ masks,
+                                                       uint32_t nwords, uint32_t nblk,
+                                                       uint32_t *__restrict__ blk_counts)
+{
+    __shared__ uint32_t wc[4];
+    const int level = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t cnt = 0;
+    for (uint32_t w = blockIdx.x * EX_WPB + threadIdx.x; w < min((blockIdx.x + 1) * (uint32_t)EX_WPB, nwords);
+         w += 256)
+        cnt += (uint32_t)__popcll(masks[(size_t)level * nwords + w]);
+    cnt = wave_sum_u32(cnt);
+    if (lane == 0)
+        wc[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        blk_counts[(size_t)level * nblk + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
 
 // exclusive scan of the block counts (all levels of the launch), continuing from *d_count
@@ -2497,7 +2641,49 @@ int sift3d_hip_extrema_mode(const sift3d_hip_extrema_level *levels, int nlevels,
         LV.lv[i] = levels[i];
     unsigned long long *masks = reinterpret_cast<unsigned long long *>(d_work);
     uint32_t *blk = reinterpret_cast<uint32_t *>(masks + (size_t)nlevels * E.nwords);
-    if (E.cuboid)
+    // default configuration (three keypoint levels sharing their DoG levels, whole quads): one z
+    // sweep over the five DoG levels instead of three scattered-neighbour passes
+    static const bool no_sweep = getenv("SIFT3D_AMD_NO_EXSWEEP") != nullptr;
+    bool sweep = !E.cuboid && !no_sweep && nlevels == 3 && (nx & 3) == 0 && nz >= 3;
+    if (sweep) {
+        const float *ptrs[5] = { levels[0].prev, levels[0].cur, levels[1].cur, levels[2].cur, levels[2].next };
+        sweep = levels[0].next == levels[1].cur && levels[1].prev == levels[0].cur &&
+                levels[1].next == levels[2].cur && levels[2].prev == levels[1].cur &&
+                levels[0].z_lo == levels[1].z_lo && levels[1].z_lo == levels[2].z_lo &&
+                levels[0].z_hi == levels[1].z_hi && levels[1].z_hi == levels[2].z_hi &&
+                levels[0].z_lo >= 1 && levels[0].z_hi <= nz - 1;
+        for (int i = 0; i < 5; i++)
+            sweep = sweep && (((uintptr_t)ptrs[i]) & 15) == 0;
+        if (sweep) {
+            ExSweep S;
+            memset(&S, 0, sizeof(S));
+            for (int i = 0; i < 5; i++)
+                S.d[i] = ptrs[i];
+            for (int i = 0; i < 3; i++)
+                S.absmax[i] = levels[i].d_absmax;
+            S.peak_thresh = peak_thresh;
+            S.nx = nx; S.ny = ny; S.nz = nz;
+            S.z_lo = levels[0].z_lo; S.z_hi = levels[0].z_hi;
+            S.wpr = E.wpr; S.nwords = E.nwords;
+            S.masks32 = reinterpret_cast<uint32_t *>(masks);
+            const int n_out = S.z_hi - S.z_lo;
+            HIPCHK(hipMemsetAsync(masks, 0, (size_t)3 * E.nwords * 8, st));
+            if (n_out > 0) {
+                const long bxy = (long)((nx + 63) / 64) * ((ny + 15) / 16);
+                long nseg = (2048 + bxy - 1) / bxy;
+                const long cap_seg = n_out / 16 > 1 ? n_out / 16 : 1;
+                nseg = nseg < cap_seg ? nseg : cap_seg;
+                S.ts = (int)((n_out + nseg - 1) / nseg);
+                dim3 grid((nx + 63) / 64, (ny + 15) / 16, (n_out + S.ts - 1) / S.ts);
+                hipLaunchKernelGGL(k_extrema_sweep3, grid, dim3(256), 0, st, S);
+            }
+            hipLaunchKernelGGL(k_extrema_count, dim3(E.nblk, 3), dim3(256), 0, st, masks, E.nwords,
+                               E.nblk, blk);
+        }
+    }
+    if (sweep)
+        ;
+    else if (E.cuboid)
         hipLaunchKernelGGL(k_extrema_mask<true>, dim3(E.nblk, nlevels), dim3(256), 0, st, LV, E, masks,
                            blk);
     else
