@@ -2825,6 +2825,8 @@ int sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d
 {
     if (!n)
         return SIFT3D_SUCCESS;
+    // diagnostic only (wrong results): 1 skips the ordered commit, 2 the whole batch -- used to
+    // attribute the kernel's time to scan / per-voxel terms / commit
     static int ablate = getenv("SIFT3D_AMD_DESC_ABLATE") ? atoi(getenv("SIFT3D_AMD_DESC_ABLATE")) : 0;
     hipLaunchKernelGGL(k_describe, dim3(n), dim3(64), 0, (hipStream_t)stream, d_levels, d_kp, n,
                        d_hist, ablate);
