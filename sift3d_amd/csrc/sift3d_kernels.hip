@@ -1733,7 +1733,7 @@ constexpr int HIST_LDS = 800;
 // record rows: voxel v of a batch sits at (v & 1) * 48 + (v >> 1) -- even voxels (first commit
 // half-wave) from 0, odd ones from 48, so both the 64-lane writes of phase A and the 16-byte
 // reads of phase B are conflict-free with a row stride of 84 floats
-constexpr int RROW = 84, RODD = 48;
+constexpr int RROW = 36, RODD = 16;   // records of HALF a batch (32 voxels): 16 even + 16 odd slots
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_describe(const sift3d_hip_level *__restrict__ levels,
                                                  const sift3d_hip_kp *__restrict__ kps, uint32_t n,
@@ -1779,7 +1779,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const int half = lane >> 5, l5 = lane & 31;
     const bool committer = l5 < 24;
     const int pc = committer ? l5 / 3 : 0, pj = committer ? l5 - 3 * pc : 0;
-    const int slot = (lane & 1) * RODD + (lane >> 1);  // where phase A puts this lane's voxel
+    const int slot = (lane & 1) * RODD + ((lane & 31) >> 1);  // where this lane's voxel goes in its half-batch
     const int pdx = (pc >> 2) & 1, pdy = (pc >> 1) & 1, pdz = pc & 1;
     const int coff4 = 4 * (pdx + 4 * pdy + 16 * pdz);  // byte offset of this lane's cell corner
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -1831,7 +1831,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         }
     };
     auto batch = [&](int cnt, const float *cv, int pk) {
-        float mwv[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+        float mwv[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, bwv[3] = { 0.f, 0.f, 0.f };
+        int abv[3] = { 0, 0, 0 };
         if (ablate & 2) return;
         if (lane < cnt) {
             const int x = B.xs + (pk & 1023), y = B.ys + ((pk >> 10) & 1023), z = B.zs + (pk >> 20);
@@ -1954,19 +1955,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
                         const float wt = ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1];
                         mwv[c] = mag * wt;
                     }
-                    bw[0][slot] = b0; bw[1][slot] = b1; bw[2][slot] = b2;
+                    bwv[0] = b0; bwv[1] = b1; bwv[2] = b2;
                     // byte addresses of the bins (base cell, face vertex j) -- the vertices
                     // addressed through the UNSWAPPED idx[] of the face (quirk Q1)
                     const int cell4 = 4 * (ix + 4 * iy + 16 * iz);
 #pragma unroll
                     for (int j = 0; j < 3; j++)
-                        ab[j][slot] = 4 * ((fidx >> (10 * j)) & 1023) + cell4;
+                        abv[j] = 4 * ((fidx >> (10 * j)) & 1023) + cell4;
                 }
             }
         }
+        // The records go through LDS half a batch at a time (voxels 0..31, then 32..63): half
+        // the record space per keypoint buys a sixth wave per SIMD.
+#pragma unroll 1
+        for (int hb2 = 0; hb2 < 2; hb2++) {
+        if ((lane >> 5) == hb2) {
 #pragma unroll
-        for (int c = 0; c < 8; c++)
-            mw[c][slot] = mwv[c];      // all zero: nothing is committed for this voxel
+            for (int c = 0; c < 8; c++)
+                mw[c][slot] = mwv[c];      // all zero: nothing is committed for this voxel
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                bw[j][slot] = bwv[j];
+                ab[j][slot] = abv[j];
+            }
+        }
         __syncthreads();
         // Ordered commit, two voxels per iteration (2i by lanes 0..23, 2i+1 by lanes 32..55).
         // 24 lanes per voxel (8 cells x 3 face vertices) each own one distinct histogram bin,
@@ -1982,10 +1994,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             float4 mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb]);
             float4 bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb]);
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
+            for (int c = 0; c < 4; c++) {
                 const int mb[4] = { mb4.x, mb4.y, mb4.z, mb4.w };
                 const float mv[4] = { mw4.x, mw4.y, mw4.z, mw4.w }, bv[4] = { bw4.x, bw4.y, bw4.z, bw4.w };
-                if (c < 7) {
+                if (c < 3) {
                     mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb + 4 * c + 4]);
                     mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb + 4 * c + 4]);
                     bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb + 4 * c + 4]);
@@ -2007,6 +2019,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             }
         }
         __syncthreads();
+        }
     };
 
     // The reference scans the whole bounding box of the sphere (sift.c:96-108).  Every voxel
