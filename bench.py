@@ -176,10 +176,18 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
     if not torch.cuda.is_available() or not api.device_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU path to measure")
+    # SIFT3D_AMD_REHEARSE=1: all ranks share device 0 and talk through gloo -- a rehearsal of
+    # the N > 1 code path on a one-GPU box (the numbers mean nothing); the real run is RCCL
+    rehearse = bool(os.environ.get("SIFT3D_AMD_REHEARSE")) and world > 1
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     hip.lib().sift3d_hip_set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = a.size
     if world == 1 and not a.sharded:
@@ -223,7 +231,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if rehearse else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -281,7 +289,7 @@ def main():
     else:
         out["roofline"] = dict(pyramid or {}, kernel="Gaussian pyramid (all k_fir_* launches)",
                                traffic=None)
-    if not a.no_cpu:
+    if not a.no_cpu and world == 1:          # the CPU leg runs at N = 1 only
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
     if world > 1:
