@@ -1462,12 +1462,21 @@ __global__ __launch_bounds__(256) void k_extrema_emit(ExLevels LV, ExGeom E,
         return;
     const uint32_t base = blk_off[(size_t)level * E.nblk + blockIdx.x];
     const size_t ys = E.nx, zs = (size_t)E.nx * E.ny;
+    // the wave's EX_WPB / 4 (<= 64) mask words: one load, lane i holds word i
+    static_assert(EX_WPB / 4 <= 64, "one word per lane");
+    unsigned long long mine = 0ull;
+    if (lane < EX_WPB / 4 && w0 + wave * (EX_WPB / 4) + lane < E.nwords)
+        mine = masks[(size_t)level * E.nwords + w0 + wave * (EX_WPB / 4) + lane];
     for (int w = 0; w < EX_WPB / 4; w++) {
         const int wi = wave * (EX_WPB / 4) + w;
         const uint32_t word = w0 + wi;
         if (word >= E.nwords)
             break;
-        const unsigned long long m = masks[(size_t)level * E.nwords + word];
+        const unsigned long long m =
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), w) << 32) |
+            (unsigned)__builtin_amdgcn_readlane((int)mine, w);
+        if (m == 0ull)
+            continue;   // wave-uniform
         if (!((m >> lane) & 1ull))
             continue;
         const uint32_t pos = base + pre[wi] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
