@@ -540,7 +540,15 @@ class ShardedSift3D:
         # window / DoG halos of the sharded octaves
         for o in range(g.o_shard):
             for s in range(g.ngl):
-                self._halo(self.G[o][s], WINDOW_HALO if 1 <= s <= g.K else 1)
+                # keypoint level s-1 (Gaussian index s): the descriptor window reaches
+                # 2 * 7.0711 * sigma0 * 2^((s-1)/K) / uz planes (sift.c:1453-1455) + 1 for the
+                # gradient; the other levels only feed the DoG / extrema neighbours
+                if 1 <= s <= g.K:
+                    need = int(math.ceil(14.1422 * self.sigma0 * 2.0 ** ((s - 1) / g.K) /
+                                         self.units[2])) + 2
+                    self._halo(self.G[o][s], min(need, WINDOW_HALO))
+                else:
+                    self._halo(self.G[o][s], 1)
         # build_dog (sift.c:713-732) + dogmax (sift.c:821-826)
         scal = []
         stack = getattr(be, "dog_stack", None)
