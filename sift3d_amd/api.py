@@ -110,7 +110,8 @@ class MatRm:
             raise MemoryError("sift3d_make_mat_rm")
 
     def free(self):
-        if self.h:
+        # (at interpreter shutdown module globals may already be gone: nothing to do then)
+        if getattr(self, "h", None) and lib is not None:
             lib().sift3d_free_mat_rm(self.h)
             self.h = None
 
@@ -179,7 +180,8 @@ class Image:
         return np.ctypeslib.as_array(p, shape=self.shape)
 
     def free(self):
-        if self.h:
+        # (at interpreter shutdown module globals may already be gone: nothing to do then)
+        if getattr(self, "h", None) and lib is not None:
             lib().sift3d_free_image(self.h)
             self.h = None
 
@@ -197,7 +199,8 @@ class KeypointStore:
         self.h = lib().sift3d_make_keypoint_store()
 
     def free(self):
-        if self.h:
+        # (at interpreter shutdown module globals may already be gone: nothing to do then)
+        if getattr(self, "h", None) and lib is not None:
             lib().sift3d_free_keypoint_store(self.h)
             self.h = None
 
@@ -252,7 +255,8 @@ class DescriptorStore:
         self.h = lib().sift3d_make_descriptor_store()
 
     def free(self):
-        if self.h:
+        # (at interpreter shutdown module globals may already be gone: nothing to do then)
+        if getattr(self, "h", None) and lib is not None:
             lib().sift3d_free_descriptor_store(self.h)
             self.h = None
 
@@ -286,7 +290,8 @@ class Detector:
                 raise ValueError("sift3d_detector_set_%s(%r) failed" % (name, v))
 
     def free(self):
-        if self.h:
+        # (at interpreter shutdown module globals may already be gone: nothing to do then)
+        if getattr(self, "h", None) and lib is not None:
             lib().sift3d_free_detector(self.h)
             self.h = None
 

@@ -463,3 +463,23 @@ def test_read_image_then_detect(gpu, oracle_mod, tmp_path):
         np.testing.assert_array_equal(k[f], ok[f], err_msg=f)
     assert util.rel_err(k["R"], ok["R"]) <= RTOL
     assert util.rel_err(desc.to_mat_rm(), o.desc_mat()) <= RTOL
+
+
+def test_repeated_runs_are_bitwise_identical(gpu):
+    """The window kernels rely on the issue order of a wave's LDS operations and on block-level
+    reductions through atomicMax only: every run must give the same bits."""
+    import hashlib
+    api, hip, torch = gpu
+    n = 160
+    vol = torch.empty((n, n, n), device="cuda")
+    hip.synth_lattice(vol, 0, 21)
+    det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+    seen = set()
+    for _ in range(6):
+        assert det.detect_keypoints_device(vol.data_ptr(), n, n, n, kp) == 0
+        assert det.extract_descriptors(kp, desc) == 0
+        k = kp.records()
+        seen.add((hashlib.sha1(desc.to_mat_rm().tobytes()).hexdigest(),
+                  hashlib.sha1(np.ascontiguousarray(k["R"]).tobytes()).hexdigest(),
+                  det.num_candidates(), len(k)))
+    assert len(seen) == 1 and next(iter(seen))[3] > 100
