@@ -305,7 +305,8 @@ def test_detect_describe_golden(gpu, oracle_mod, name):
         np.testing.assert_array_equal(k2["strength"], g["sort%d_strength" % lim])
 
 
-@pytest.mark.parametrize("n,gen", [(96, "survey"), (160, "lattice"), ((100, 72, 90), "survey")])
+@pytest.mark.parametrize("n,gen", [(96, "survey"), (160, "lattice"), ((100, 72, 90), "survey"),
+                                   ((130, 126, 122), "lattice")])   # last: no dimension a multiple of 4
 def test_detect_describe_vs_oracle(gpu, oracle_mod, n, gen):
     api, hip, torch = gpu
     vol = oracle_mod.synth_survey(n) if gen == "survey" else oracle_mod.synth_lattice(n, seed=3)
