@@ -1712,26 +1712,37 @@ __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restric
 // ---------------------------------------------------------------------------------------
 // extract_descrip  (sift.c:1442-1536): one wave per keypoint.
 //
-// Phase A (64 voxels in parallel): window test, gradient, Gaussian weight, rotation into
-// keypoint space, icosahedron face + barycentrics, the eight trilinear cell weights.
-// Phase B (ordered): for each valid voxel in scan order, 24 lanes (8 cells x 3 face
-// vertices) add mag*w_cell*bary_j into the 768-bin LDS histogram with ds_add_f32.  DS
-// operations of one wave execute in issue order, so every bin receives its contributions
-// in the reference's order and the float sums are bit-identical to the CPU loop.
+// Scan    (64 voxels in parallel): exact window test, survivors stream-compacted into an LDS
+//         queue so that the expensive phases always run on 64 window voxels.
+// Phase A (one lane per voxel): gradient, Gaussian weight, rotation into keypoint space,
+//         icosahedron face + barycentrics, the eight trilinear cell weights -- the reference's
+//         float expressions, so every per-voxel DECISION (window, |g| threshold, face, skipped
+//         corner) and every per-voxel VALUE is the reference's bit for bit.
+// Phase B (commit): a voxel adds mag*w_cell*bary_j to 24 distinct bins (8 cells x 3 face
+//         vertices), which 24 lanes do as ONE plain LDS read-modify-write.  The two half-waves
+//         commit two voxels per round into two PRIVATE histograms, which are added at the end.
+//
+// Accumulation order: the reference adds voxels in scan order (z, y, x).  Here every 64-voxel
+// batch is cut into four runs of 16 consecutive voxels; half-wave 0 adds runs 0 and 2 to its
+// histogram, half-wave 1 runs 1 and 3 to its own, and the two partial histograms are merged as
+// h0 + h1.  The order is fixed by the keypoint alone (not by timing), so results are bitwise
+// reproducible run to run; against the reference they differ by summation order only: the terms
+// of a bin are >= -1e-6 * |term|, so the relative error of a bin is a few float ulps
+// (BASELINE's bar: 1e-5 relative).
+// LDS float atomics are not an option on gfx950: ds_add_f32 retires ~0.3 lane-adds/clk/CU
+// (measured, scratch microbenchmark), 20x slower than the read-modify-write below.
 // ---------------------------------------------------------------------------------------
 struct FaceRec {
     float v0[3], e1[3], e2[3], t[3], q[3], e2q, idx[3];
 };
 static_assert(sizeof(FaceRec) == SIFT3D_HIP_FACE_FLOATS * 4, "face record layout");
 
-// per-face constants as the kernel wants them: e1, e2, t, q, e2.q (+3 pad) = 16 floats
+// per-face constants as the kernel wants them: e1, e2, t, q, e2.q, packed bin offsets (+2 pad)
 __constant__ float c_face16[20 * 16];
-__constant__ int c_face_idx[60];   // unswapped vertex ids of each face (bins, quirk Q1)
 __constant__ int c_bin_off[12];    // LDS offset of each vertex's 64-cell block (see k_describe)
-__constant__ float c_verts[12 * 3];// unit vertices
-__constant__ int c_vert_faces[12 * 5]; // the five faces around each vertex, ascending
-__constant__ int c_vf5[12];        // the same, 5 bits per face
-__constant__ int c_vmask[12];      // the same, as a 20-bit face mask
+// face that contains a direction, by sign octant (bit 0/1/2 = x/y/z negative) and position
+// relative to the octant's central face: see icos_guess
+__constant__ int c_oct_face[32];
 
 constexpr int DQ = 128; // compaction queue length (power of two, >= 2 * 64)
 // LDS histogram: bin (cell, vertex) lives at c_bin_off[vertex] + cell, cell = ix + 4*iy + 16*iz.
@@ -1739,23 +1750,71 @@ constexpr int DQ = 128; // compaction queue length (power of two, >= 2 * 64)
 // icosahedron's vertices, which puts the 24 bins of any voxel (8 neighbouring cells x the 3
 // vertices of a face) on 24 different banks of the 32 that ds_read_b32/ds_write_b32 use.
 constexpr int HIST_LDS = 800;
-// record rows: voxel v of a batch sits at (v & 1) * 48 + (v >> 1) -- even voxels (first commit
-// half-wave) from 0, odd ones from 48, so both the 64-lane writes of phase A and the 16-byte
-// reads of phase B are conflict-free with a row stride of 84 floats
-constexpr int RROW = 36, RODD = 16;   // records of HALF a batch (32 voxels): 16 even + 16 odd slots
+// Phase A -> phase B records, field-major: row f holds field f of half a batch (32 voxels; the
+// records go through LDS half a batch at a time, which keeps a fourth wave per SIMD resident).
+// Rows are 36 floats apart: the eight rows that the 24 committer lanes of a half-wave read with
+// ds_read_b128 (four voxels at a time) fall on disjoint bank quads.
+constexpr int RROW = 36;
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_describe(const sift3d_hip_level *__restrict__ levels,
-                                                 const sift3d_hip_kp *__restrict__ kps, uint32_t n,
-                                                 float *__restrict__ out, int ablate)
+#ifdef SIFT3D_AMD_DIAG
+#define DESC_ABLATE_ARG , int ablate
+#define DESC_ABLATE(bit) (ablate & (bit))
+#else
+#define DESC_ABLATE_ARG
+#define DESC_ABLATE(bit) false
+#endif
+
+// cart2bary + the acceptance test of icos_hist_bin (sift.c:276-297, 1268-1286) for one face,
+// the reference's float expressions.  fr: the face's 16-float record (LDS).
+__device__ __forceinline__ bool face_eval(const float4 *__restrict__ fr, float rx, float ry, float rz,
+                                          float &xb, float &yb, float &zb, int &fi)
 {
-    __shared__ float hist[HIST_LDS];
-    // Phase A -> phase B records of the batch's 64 voxels, each commit half-wave reading ITS
-    // voxels contiguously
+    const float4 A0 = fr[0], A1 = fr[1], A2 = fr[2], A3 = fr[3];
+    // e1 = A0.xyz, e2 = (A0.w, A1.x, A1.y), t = (A1.z, A1.w, A2.x),
+    // q = (A2.y, A2.z, A2.w), e2.q = A3.x, bin offsets = A3.y
+    const float px = ry * A1.y - rz * A1.x;        // p = g x e2, sift.c:278
+    const float py = rz * A0.w - rx * A1.y;
+    const float pz = rx * A1.x - ry * A0.w;
+    const float det = A0.x * px + A0.y * py + A0.z * pz;
+    const float di = 1.0f / det;
+    yb = di * (A1.z * px + A1.w * py + A2.x * pz);
+    zb = di * (rx * A2.y + ry * A2.z + rz * A2.w);
+    xb = 1.0f - yb - zb;
+    const float kk = A3.x * di;
+    fi = __float_as_int(A3.y);
+    return !(fabsf(det) < 1.1920928955078125e-06f) &&            // sift.c:282
+           !(xb < -1.1920928955078125e-06f || yb < -1.1920928955078125e-06f ||
+             zb < -1.1920928955078125e-06f || kk < 0);            // sift.c:1277-1279
+}
+
+// A GUESS of the face a direction falls in (no decision rests on it: the caller verifies the
+// guess with face_eval and falls back to the reference's full face scan).  The vertex set
+// (0,+-1,+-g), (+-1,+-g,0), (+-g,0,+-1) is symmetric under sign flips, so the direction is
+// reflected into the positive octant, which holds the face C = {(0,1,g), (1,g,0), (g,0,1)}
+// and one third each of the three faces across C's edges; t1..t3 are the signed distances to
+// the planes through the origin and C's edges.
+__device__ __forceinline__ int icos_guess(float rx, float ry, float rz)
+{
+    const float g = 1.6180339887f, g2 = 2.6180339887f;
+    const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
+    const float t1 = ax + g2 * ay - g * az;      // edge (0,1,g)-(g,0,1), beyond: face with (0,-1,g)
+    const float t2 = ay + g2 * az - g * ax;      // edge (g,0,1)-(1,g,0), beyond: face with (g,0,-1)
+    const float t3 = az + g2 * ax - g * ay;      // edge (1,g,0)-(0,1,g), beyond: face with (-1,g,0)
+    const int cls = t1 < 0.0f ? 1 : (t2 < 0.0f ? 2 : (t3 < 0.0f ? 3 : 0));
+    return cls * 8 + (rx < 0.0f ? 1 : 0) + (ry < 0.0f ? 2 : 0) + (rz < 0.0f ? 4 : 0);
+}
+
+__global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restrict__ levels,
+                                                 const sift3d_hip_kp *__restrict__ kps, uint32_t n,
+                                                 float *__restrict__ out DESC_ABLATE_ARG)
+{
+    __shared__ float hist[2 * HIST_LDS];   // one private histogram per half-wave
     __shared__ __attribute__((aligned(16))) float mw[8][RROW]; // mag * trilinear weight of the eight cells
     __shared__ __attribute__((aligned(16))) float bw[3][RROW]; // barycentric weights
-    __shared__ __attribute__((aligned(16))) int ab[3][RROW];   // byte address of bin (base cell, face vertex j) in hist
+    __shared__ __attribute__((aligned(16))) int ab[3][RROW];   // byte address of bin (base cell, face vertex j)
+    __shared__ __attribute__((aligned(16))) float sface[20 * 16]; // c_face16 (per-lane face index)
     __shared__ int queue[DQ];     // xx | yy<<10 | zz<<20, window-relative, in scan order
-    __shared__ int svm[12], svf[12]; // faces around each vertex: 20-bit mask / five 5-bit ids
+    __shared__ int soct[32];      // c_oct_face
     const uint32_t ki = blockIdx.x;
     if (ki >= n)
         return;
@@ -1763,12 +1822,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const sift3d_hip_kp K = kps[ki];
     const sift3d_hip_level L = levels[K.level];
     const uint32_t orow = K.row1 ? K.row1 - 1 : ki;   // output row (launch order may differ)
-    for (int i = lane; i < HIST_LDS; i += 64)
+    for (int i = lane; i < 2 * HIST_LDS; i += 64)
         hist[i] = 0.0f;
-    if (lane < 12) {
-        svm[lane] = c_vmask[lane];
-        svf[lane] = c_vf5[lane];
-    }
+    for (int i = lane; i < 20 * 16; i += 64)
+        sface[i] = c_face16[i];
+    if (lane < 32)
+        soct[lane] = c_oct_face[lane];
 
     const float sigma = (float)(K.sd * 7.071067812);                  // sift.c:1453
     const float rad = (float)(2.0 * (double)sigma);                   // sift.c:1454
@@ -1779,18 +1838,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const float rad2 = rad * rad;
     const float sig2 = sigma * sigma;
     const float *R = K.R; // Rt[i][j] = R[j][i]
+    const float iux = 1.0f / L.ux, iuy = 1.0f / L.uy, iuz = 1.0f / L.uz;
     Box B;
     bounds_f(K.cx, rad, L.ux, L.nx, B.xs, B.xe);
     bounds_f(K.cy, rad, L.uy, L.ny, B.ys, B.ye);
     bounds_f(K.cz, rad, L.uz, L.nz_glob, B.zs, B.ze);
-    // phase B roles: lanes 0..23 commit the first voxel of a pair, lanes 32..55 the second;
-    // each committer lane is one (trilinear cell corner, face vertex) pair
+    // phase B roles: each half-wave commits one voxel per round; its lanes 0..23 are the
+    // (trilinear cell corner, face vertex) pairs of that voxel.  Lanes 24..31 repeat lane 0's
+    // work (same address, same value: harmless), which keeps the commit free of predication.
     const int half = lane >> 5, l5 = lane & 31;
-    const bool committer = l5 < 24;
-    const int pc = committer ? l5 / 3 : 0, pj = committer ? l5 - 3 * pc : 0;
-    const int slot = (lane & 1) * RODD + ((lane & 31) >> 1);  // where this lane's voxel goes in its half-batch
+    const int pc = l5 < 24 ? l5 / 3 : 0, pj = l5 < 24 ? l5 - 3 * pc : 0;
     const int pdx = (pc >> 2) & 1, pdy = (pc >> 1) & 1, pdz = pc & 1;
-    const int coff4 = 4 * (pdx + 4 * pdy + 16 * pdz);  // byte offset of this lane's cell corner
+    // byte offset of this lane's cell corner, in this half-wave's histogram
+    const int coff4 = 4 * (pdx + 4 * pdy + 16 * pdz) + half * (HIST_LDS * 4);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     __syncthreads();
 
@@ -1804,8 +1864,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         const float dy = ((float)y - K.cy) * L.uy;
         const float dz = ((float)z - K.cz) * L.uz;
         sq = dx * dx + dy * dy + dz * dz;
-        if (sq > rad2)                                             // sift.c:106 (float)
-            return false;
         // vkp = Rt * vim (immacros.h:328-340)
         const float kx = R[0] * dx + R[3] * dy + R[6] * dz;
         const float ky = R[1] * dx + R[4] * dy + R[7] * dz;
@@ -1813,7 +1871,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         vbx = (kx + half_w) * bin_f;                               // sift.c:1483-1485
         vby = (ky + half_w) * bin_f;
         vbz = (kz + half_w) * bin_f;
-        return !(vbx < 0 || vby < 0 || vbz < 0 || vbx >= 4.0f || vby >= 4.0f ||
+        return !(sq > rad2) &&                                     // sift.c:106 (float)
+               !(vbx < 0 || vby < 0 || vbz < 0 || vbx >= 4.0f || vby >= 4.0f ||
                  vbz >= 4.0f);                                     // sift.c:1488-1492
     };
 
@@ -1831,8 +1890,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
             const float *p = L.data + (size_t)x + ys * y + zs * zl;
             pv[0] = p[1]; pv[1] = *(p - 1); pv[2] = p[ys]; pv[3] = *(p - ys);
             pv[4] = p[zs]; pv[5] = *(p - zs);
-            // the Gaussian weight only needs the coordinates: its table look-up (constant
-            // memory) also flies one batch ahead
+            // the Gaussian weight only needs the coordinates: it also flies one batch ahead
             const float dx = ((float)x - K.cx) * L.ux;                 // sift.c:102-104
             const float dy = ((float)y - K.cy) * L.uy;
             const float dz = ((float)(B.zs + (ppk >> 20)) - K.cz) * L.uz;
@@ -1842,192 +1900,125 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     auto batch = [&](int cnt, const float *cv, int pk) {
         float mwv[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, bwv[3] = { 0.f, 0.f, 0.f };
         int abv[3] = { 0, 0, 0 };
-        if (ablate & 2) return;
-        if (lane < cnt) {
+        if (DESC_ABLATE(2)) return;
+        {
+            // (lanes beyond cnt compute on stale coordinates and are discarded below)
             const int x = B.xs + (pk & 1023), y = B.ys + ((pk >> 10) & 1023), z = B.zs + (pk >> 20);
             float sq, vbx, vby, vbz;
             window(x, y, z, sq, vbx, vby, vbz);
             // IM_GET_GRAD_ISO (sift.c:140-145, immacros.h:105-111)
             float gx = 0.5f * (cv[0] - cv[1]), gy = 0.5f * (cv[2] - cv[3]), gz = 0.5f * (cv[4] - cv[5]);
-            gx *= 1.0f / L.ux;
-            gy *= 1.0f / L.uy;
-            gz *= 1.0f / L.uz;
+            gx *= iux;
+            gy *= iuy;
+            gz *= iuz;
             const float w = cv[6];                                 // sift.c:1498, see prefetch
             gx = gx * w; gy = gy * w; gz = gz * w;
             const float rx = R[0] * gx + R[3] * gy + R[6] * gz;    // sift.c:1502
             const float ry = R[1] * gx + R[4] * gy + R[7] * gz;
             const float rz = R[2] * gx + R[5] * gy + R[8] * gz;
             const float m2 = rx * rx + ry * ry + rz * rz;
-            if (!(m2 < 1.1920928955078125e-06f)) {                 // sift.c:1264
-                // icos_hist_bin (sift.c:1268-1286): the first face in table order whose
-                // barycentrics are >= -eps wins.  A face can only pass if the ray hits it or
-                // misses it by ~eps, so the candidates are the two faces on the edge between the
-                // two icosahedron vertices nearest to the ray (ascending order, cart2bary's
-                // arithmetic).  Within ~1e-3 rad of a vertex -- where more than two faces are
-                // within eps -- and whenever that shortcut finds nothing, all five faces
-                // around the nearest vertex are tried instead.
-                //
-                // Nearest two vertices: the vertices are (0,+-1,+-g), (+-1,+-g,0), (+-g,0,+-1)
-                // (ids 0-3, 4-7, 8-11; bit 0 / bit 1 of the id = sign of the first / second
-                // non-zero coordinate), so the best vertex of a family has the ray's signs and
-                // its runner-up flips the sign of the smaller term.
-                const float gr = 1.6180339887f;
-                const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
-                const float hx = gr * ax, hy = gr * ay, hz = gr * az;
-                const int sxn = rx < 0.0f, syn = ry < 0.0f, szn = rz < 0.0f;
-                const float s0 = ay + hz, s1 = ax + hy, s2 = hx + az;
-                const int i0 = syn + 2 * szn, i1 = 4 + sxn + 2 * syn, i2 = 8 + sxn + 2 * szn;
-                const float f0 = s0 - 2.0f * fminf(ay, hz), f1 = s1 - 2.0f * fminf(ax, hy),
-                            f2 = s2 - 2.0f * fminf(hx, az);
-                const int a0 = i0 ^ (ay <= hz ? 1 : 2), a1 = i1 ^ (ax <= hy ? 1 : 2),
-                          a2 = i2 ^ (hx <= az ? 1 : 2);
-                const bool b01 = s0 >= s1;
-                const float t = b01 ? s0 : s1, l = b01 ? s1 : s0, tf = b01 ? f0 : f1;
-                const int ti = b01 ? i0 : i1, li = b01 ? i1 : i0, ta = b01 ? a0 : a1;
-                const bool bt = t >= s2;
-                const int vs = bt ? ti : i2;                       // nearest vertex
-                const float best = bt ? t : s2;
-                // runner-up: best of (other families' winners, the winner family's flip)
-                float c1 = bt ? l : t, c2 = bt ? s2 : f2, c3 = bt ? tf : -1.0f;
-                int d1 = bt ? li : ti, d2 = bt ? i2 : a2, d3 = bt ? ta : 0;
-                if (c2 > c1) { c1 = c2; d1 = d2; }
-                if (c3 > c1) { c1 = c3; d1 = d3; }
-                const int vs2 = d1;
-
-                int face = -1, fidx = 0;
-                float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-                auto eval = [&](int f, float &xb, float &yb, float &zb, int &fi) -> bool {
-                    // (the tables stay in constant memory: LDS is what limits the number of
-                    // keypoints in flight per CU)
-                    const float4 *fr = reinterpret_cast<const float4 *>(c_face16) + f * 4;
-                    const float4 A0 = fr[0], A1 = fr[1], A2 = fr[2], A3 = fr[3];
-                    // e1 = A0.xyz, e2 = (A0.w, A1.x, A1.y), t = (A1.z, A1.w, A2.x),
-                    // q = (A2.y, A2.z, A2.w), e2.q = A3.x, bin offsets = A3.y
-                    const float px = ry * A1.y - rz * A1.x;        // p = g x e2, sift.c:278
-                    const float py = rz * A0.w - rx * A1.y;
-                    const float pz = rx * A1.x - ry * A0.w;
-                    const float det = A0.x * px + A0.y * py + A0.z * pz;
-                    const float di = 1.0f / det;
-                    yb = di * (A1.z * px + A1.w * py + A2.x * pz);
-                    zb = di * (rx * A2.y + ry * A2.z + rz * A2.w);
-                    xb = 1.0f - yb - zb;
-                    const float kk = A3.x * di;
-                    fi = __float_as_int(A3.y);
-                    return !(fabsf(det) < 1.1920928955078125e-06f) &&            // sift.c:282
-                           !(xb < -1.1920928955078125e-06f || yb < -1.1920928955078125e-06f ||
-                             zb < -1.1920928955078125e-06f || kk < 0);            // sift.c:1277-1279
-                };
-                const int pairm = svm[vs] & svm[vs2];
-                // cos^2 of the angle to the nearest vertex > 1 - 2e-6  (|vertex|^2 = 1 + g^2)
-                bool slow = __popc(pairm) != 2 || best * best > m2 * (3.6180339887f * (1.0f - 2e-6f));
-                if (!slow) {
-                    const int fa = __ffs(pairm) - 1, fb = __ffs(pairm & (pairm - 1)) - 1;
-                    float xa, ya, za, xc, yc, zc;
-                    int ia, ic;
-                    const bool pa = eval(fa, xa, ya, za, ia), pb = eval(fb, xc, yc, zc, ic);
-                    if (pa) {
-                        face = fa; b0 = xa; b1 = ya; b2 = za; fidx = ia;
-                    } else if (pb) {
-                        face = fb; b0 = xc; b1 = yc; b2 = zc; fidx = ic;
-                    } else {
-                        slow = true;
-                    }
-                }
-                if (slow) {
-                    const int five = svf[vs];
+            const bool live = lane < cnt && !(m2 < 1.1920928955078125e-06f);   // sift.c:1264
+            // icos_hist_bin (sift.c:1268-1286): the first face in table order whose barycentrics
+            // are >= -eps wins.  A face other than the one the ray really crosses can only pass
+            // if the ray misses it by ~eps, i.e. if the ray is within ~eps of an edge of its own
+            // face.  So: guess the face, evaluate it with cart2bary's arithmetic, and accept it
+            // when it passes with all barycentrics > 2e-5 (then every other face fails by a wide
+            // margin and the first match is unique); anything else -- ~1e-4 of the voxels --
+            // takes the reference's scan over all 20 faces.
+            int fidx = 0;
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            const int f0 = soct[icos_guess(rx, ry, rz)];
+            bool found = face_eval(reinterpret_cast<const float4 *>(sface) + f0 * 4, rx, ry, rz, b0, b1,
+                                   b2, fidx) &&
+                         fminf(b0, fminf(b1, b2)) > 2e-5f;
+            if (__builtin_expect(__ballot(live && !found) != 0ull, 0)) {
+                bool open = live && !found;
 #pragma unroll 1
-                    for (int k = 0; k < 5; k++) {
-                        const int f = (five >> (5 * k)) & 31;
-                        float xb, yb, zb;
-                        int fi;
-                        if (eval(f, xb, yb, zb, fi)) {
-                            face = f; b0 = xb; b1 = yb; b2 = zb; fidx = fi;
-                            break;
-                        }
+                for (int f = 0; f < 20; f++) {
+                    float xb, yb, zb;
+                    int fi;
+                    const bool hit = face_eval(reinterpret_cast<const float4 *>(sface) + f * 4, rx,
+                                               ry, rz, xb, yb, zb, fi);
+                    if (open && hit) {
+                        b0 = xb; b1 = yb; b2 = zb; fidx = fi;
+                        found = true;
+                        open = false;
                     }
-                }
-                if (face >= 0) {
-                    const float mag = sqrtf(m2);                   // sift.c:1331
-                    const float fx = vbx - floorf(vbx);            // sift.c:1318-1320
-                    const float fy = vby - floorf(vby);
-                    const float fz = vbz - floorf(vbz);
-                    // A corner beyond the last cell is skipped by the reference (sift.c:1349-1352);
-                    // here its weight is forced to 0 and phase B skips zero weights -- adding
-                    // mag * 0 * bary = +-0 would not change a (non-negative) bin either.
-                    const int ix = (int)vbx, iy = (int)vby, iz = (int)vbz;
-                    const float ax[2] = { 1.0f - fx, ix < 3 ? fx : 0.0f },
-                                ay[2] = { 1.0f - fy, iy < 3 ? fy : 0.0f },
-                                az[2] = { 1.0f - fz, iz < 3 ? fz : 0.0f };
-#pragma unroll
-                    for (int c = 0; c < 8; c++) {
-                        // weight = wx * wy * wz (sift.c:1361-1363); value = mag * weight * bary
-                        const float wt = ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1];
-                        mwv[c] = mag * wt;
-                    }
-                    bwv[0] = b0; bwv[1] = b1; bwv[2] = b2;
-                    // byte addresses of the bins (base cell, face vertex j) -- the vertices
-                    // addressed through the UNSWAPPED idx[] of the face (quirk Q1)
-                    const int cell4 = 4 * (ix + 4 * iy + 16 * iz);
-#pragma unroll
-                    for (int j = 0; j < 3; j++)
-                        abv[j] = 4 * ((fidx >> (10 * j)) & 1023) + cell4;
+                    if (__ballot(open) == 0ull)
+                        break;
                 }
             }
+            if (live && found) {
+                const float mag = sqrtf(m2);                   // sift.c:1331
+                const float fx = vbx - floorf(vbx);            // sift.c:1318-1320
+                const float fy = vby - floorf(vby);
+                const float fz = vbz - floorf(vbz);
+                // A corner beyond the last cell is skipped by the reference (sift.c:1349-1352);
+                // here its weight is forced to 0: adding mag * 0 * bary = +-0 does not change a
+                // bin.
+                const int ix = (int)vbx, iy = (int)vby, iz = (int)vbz;
+                const float ax[2] = { 1.0f - fx, ix < 3 ? fx : 0.0f },
+                            ay[2] = { 1.0f - fy, iy < 3 ? fy : 0.0f },
+                            az[2] = { 1.0f - fz, iz < 3 ? fz : 0.0f };
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    // weight = wx * wy * wz (sift.c:1361-1363); value = mag * weight * bary
+                    const float wt = ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1];
+                    mwv[c] = mag * wt;
+                }
+                bwv[0] = b0; bwv[1] = b1; bwv[2] = b2;
+                // byte addresses of the bins (base cell, face vertex j) -- the vertices
+                // addressed through the UNSWAPPED idx[] of the face (quirk Q1)
+                const int cell4 = 4 * (ix + 4 * iy + 16 * iz);
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    abv[j] = 4 * ((fidx >> (10 * j)) & 1023) + cell4;
+            }
         }
-        // The records go through LDS half a batch at a time (voxels 0..31, then 32..63): half
-        // the record space per keypoint buys a sixth wave per SIMD.
+        // Records go through LDS half a batch at a time.  Voxels without a contribution carry
+        // zero weights and bin address 0: the commit adds 0 to a valid bin for them.
 #pragma unroll 1
         for (int hb2 = 0; hb2 < 2; hb2++) {
-        if ((lane >> 5) == hb2) {
+            if (half == hb2) {
 #pragma unroll
-            for (int c = 0; c < 8; c++)
-                mw[c][slot] = mwv[c];      // all zero: nothing is committed for this voxel
+                for (int c = 0; c < 8; c++)
+                    mw[c][l5] = mwv[c];
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                bw[j][slot] = bwv[j];
-                ab[j][slot] = abv[j];
-            }
-        }
-        __syncthreads();
-        // Ordered commit, two voxels per iteration (2i by lanes 0..23, 2i+1 by lanes 32..55).
-        // 24 lanes per voxel (8 cells x 3 face vertices) each own one distinct histogram bin,
-        // so a voxel's 24 adds are ONE plain LDS read-modify-write; the first voxel's RMW is
-        // issued before the second's and a wave's DS operations execute in issue order, so every
-        // bin receives its contributions in the reference's voxel order (sift.c:1340-1373) and
-        // the float sums are bit-identical.  (LDS float atomics would also be ordered but retire
-        // < 1 lane-add/clk/CU.)  The records of four iterations are read with three 16-byte
-        // loads, one chunk ahead of the dependent RMW chain.
-        if (!(ablate & 1)) {
-            const int hb = half * RODD;
-            int4 mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb]);
-            float4 mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb]);
-            float4 bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb]);
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int mb[4] = { mb4.x, mb4.y, mb4.z, mb4.w };
-                const float mv[4] = { mw4.x, mw4.y, mw4.z, mw4.w }, bv[4] = { bw4.x, bw4.y, bw4.z, bw4.w };
-                if (c < 3) {
-                    mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb + 4 * c + 4]);
-                    mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb + 4 * c + 4]);
-                    bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb + 4 * c + 4]);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const bool on = committer && mv[u] != 0.0f;                    // sift.c:1349-1352
-                    float *bin = reinterpret_cast<float *>(reinterpret_cast<char *>(hist) + (mb[u] + coff4));
-                    const float val = mv[u] * bv[u];                               // sift.c:1371-1373
-                    if (half == 0 && on)
-                        *bin = *bin + val;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (half == 1 && on)
-                        *bin = *bin + val;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                for (int j = 0; j < 3; j++) {
+                    bw[j][l5] = bwv[j];
+                    ab[j][l5] = abv[j];
                 }
             }
-        }
-        __syncthreads();
+            __syncthreads();
+            // Commit: round u adds voxel u of the half batch (half-wave 0) and voxel 16 + u
+            // (half-wave 1), each into its half-wave's own histogram.  The 24 lanes of a voxel
+            // own 24 distinct bins (8 cells x 3 face vertices), so the voxel's adds are ONE plain
+            // LDS read-modify-write; the DS operations of a wave execute in issue order, so
+            // round u + 1 sees round u's sums.  Records of four rounds are read with three
+            // 16-byte loads, one chunk ahead.
+            if (!DESC_ABLATE(1)) {
+                const int hb = half * 16;
+                int4 mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb]);
+                float4 mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb]);
+                float4 bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb]);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int mb[4] = { mb4.x, mb4.y, mb4.z, mb4.w };
+                    const float mv[4] = { mw4.x, mw4.y, mw4.z, mw4.w }, bv[4] = { bw4.x, bw4.y, bw4.z, bw4.w };
+                    if (c < 3) {
+                        mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb + 4 * c + 4]);
+                        mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb + 4 * c + 4]);
+                        bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb + 4 * c + 4]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        float *bin = reinterpret_cast<float *>(reinterpret_cast<char *>(hist) + (mb[u] + coff4));
+                        const float val = mv[u] * bv[u];                               // sift.c:1371-1373
+                        *bin = *bin + val;
+                    }
+                }
+            }
+            __syncthreads();
         }
     };
 
@@ -2035,7 +2026,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     // that passes the window test lies in the sphere AND in the rotated 4x4x4 cube, so each
     // plane only needs the voxels of a (conservative: +1 voxel, +0.1 %) rectangle around the
     // plane's disc, clipped to the cube's extent along the image axes; the exact per-voxel
-    // test and the scan order are unchanged.
+    // test decides.
     const float cube_x = half_w * (fabsf(R[0]) + fabsf(R[1]) + fabsf(R[2])) * 1.001f;
     const float cube_y = half_w * (fabsf(R[3]) + fabsf(R[4]) + fabsf(R[5])) * 1.001f;
     const float cube_z = half_w * (fabsf(R[6]) + fabsf(R[7]) + fabsf(R[8])) * 1.001f;
@@ -2050,19 +2041,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         const int pbx = pxe - pxs + 1, pby = pye - pys + 1;
         const int ppl = pbx > 0 && pby > 0 ? pbx * pby : 0;
         const int ox = pxs - B.xs, oy = pys - B.ys;
-        // (yy, xx) of this lane's voxel in the rectangle, advanced by 64 per chunk without a division
+        // (yy, xx) of this lane's voxel in the rectangle; a chunk of 64 voxels further it is
+        // (yy + q64, xx + r64), one more row if xx wraps
+        const int q64 = pbx > 0 ? 64 / pbx : 0, r64 = pbx > 0 ? 64 - q64 * pbx : 0;
         int yy = pbx > 0 ? lane / pbx : 0, xx = pbx > 0 ? lane - yy * pbx : 0;
         for (int c0 = 0; c0 < ppl; c0 += 64) {
-            const int i = c0 + lane;
-            bool in = false;
-            int pk = 0;
-            if (i < ppl) {
-                float sq, vbx, vby, vbz;
-                in = window(pxs + xx, pys + yy, z, sq, vbx, vby, vbz);
-                pk = (ox + xx) | ((oy + yy) << 10) | ((z - B.zs) << 20);
-            }
-            xx += 64;
-            while (xx >= pbx) {
+            float sq, vbx, vby, vbz;
+            const bool in = window(pxs + xx, pys + yy, z, sq, vbx, vby, vbz) && c0 + lane < ppl;
+            const int pk = (ox + xx) | ((oy + yy) << 10) | ((z - B.zs) << 20);
+            xx += r64;
+            yy += q64;
+            if (xx >= pbx) {
                 xx -= pbx;
                 yy++;
             }
@@ -2116,22 +2105,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         }
     }
     __syncthreads();
-    // normalize_desc -> clamp -> normalize_desc (sift.c:1402-1429, 1514-1526).  The double
-    // sum runs in element order (bin = cell * 12 + vertex) on every lane (uniform), as in the
-    // reference.
+    // The two half-wave histograms are merged in a fixed order, then normalize_desc -> clamp ->
+    // normalize_desc (sift.c:1402-1429, 1514-1526).  The reference sums the 768 squares in
+    // double in element order; here every lane sums its 12-13 slots and the 64 partial sums are
+    // combined by a fixed butterfly (reproducible; the double sum agrees to ~1e-16 relative).
     const float trunc = 0.2f * 128.0f / 768.0f;                               // sift.c:45
+    for (int i = lane; i < HIST_LDS; i += 64)
+        hist[i] = hist[i] + hist[HIST_LDS + i];
+    __syncthreads();
     for (int pass = 0; pass < 2; pass++) {
         double norm = 0.0;
-        for (int cell = 0; cell < 64; cell++)
-            for (int v = 0; v < 12; v++) {
-                const float el = hist[c_bin_off[v] + cell];
-                norm += (double)el * (double)el;
-            }
+        for (int i = lane; i < HIST_LDS; i += 64) {
+            const float el = hist[i];                                         // unused slots hold 0
+            norm += (double)el * (double)el;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            norm += __shfl_xor(norm, o, 64);
         norm = sqrt(norm) + 2.220446049250313e-16;                            // DBL_EPSILON
         const float inv = (float)(1.0 / norm);                                // 1.0f / norm
         __syncthreads();
         for (int i = lane; i < HIST_LDS; i += 64) {
-            float el = hist[i] * inv;                                         // unused slots hold 0
+            float el = hist[i] * inv;
             if (pass == 0)
                 el = el < trunc ? el : trunc;                                 // sift.c:1520
             hist[i] = el;
@@ -2730,42 +2725,44 @@ int sift3d_hip_orient(const sift3d_hip_level *d_levels, const sift3d_hip_cand *d
     return SIFT3D_SUCCESS;
 }
 
+// host twin of face_eval's acceptance test (same float expressions; this file is compiled with
+// FP contraction off for the host as well)
+static bool host_face_pass(const float *f16, int f, const float *r)
+{
+    const float *A = f16 + f * 16;
+    const float px = r[1] * A[5] - r[2] * A[4];
+    const float py = r[2] * A[3] - r[0] * A[5];
+    const float pz = r[0] * A[4] - r[1] * A[3];
+    const float det = A[0] * px + A[1] * py + A[2] * pz;
+    if (fabsf(det) < 1.1920928955078125e-06f)
+        return false;
+    const float di = 1.0f / det;
+    const float yb = di * (A[6] * px + A[7] * py + A[8] * pz);
+    const float zb = di * (r[0] * A[9] + r[1] * A[10] + r[2] * A[11]);
+    const float xb = 1.0f - yb - zb;
+    const float kk = A[12] * di;
+    return !(xb < -1.1920928955078125e-06f || yb < -1.1920928955078125e-06f ||
+             zb < -1.1920928955078125e-06f || kk < 0);
+}
+
 int sift3d_hip_set_mesh(const float *faces)
 {
-    int idx[60], vfaces[60], cnt[12];
-    float f16[20 * 16], verts[36];
+    int idx[60], cnt[12];
+    float f16[20 * 16];
     memset(f16, 0, sizeof(f16));
     memset(cnt, 0, sizeof(cnt));
-    memset(verts, 0, sizeof(verts));
     for (int f = 0; f < 20; f++) {
         const float *r = faces + f * SIFT3D_HIP_FACE_FLOATS;
         for (int j = 0; j < 3; j++)
             idx[f * 3 + j] = (int)r[16 + j];
         memcpy(f16 + f * 16, r + 3, sizeof(float) * 13); // e1, e2, t, q, e2.q
-        // unit vertices by id: the stored v0 is vertex idx[1] when the face was flipped for an
-        // outward normal and idx[0] otherwise (init_geometry, sift.c:237-241); e1 = v1 - v0 and
-        // e2 = v2 - v0 recover the other two exactly enough for a nearest-vertex search
         for (int j = 0; j < 3; j++) {
             const int id = idx[f * 3 + j];
             if (id < 0 || id >= 12 || cnt[id] >= 5) {
                 snprintf(g_err, sizeof(g_err), "sift3d_hip_set_mesh: malformed face table");
                 return SIFT3D_FAILURE;
             }
-            vfaces[id * 5 + cnt[id]++] = f; // faces visited in ascending order
-        }
-    }
-    // vertex coordinates: match each vertex id to one of the face's three stored corners by
-    // the golden-ratio pattern is unnecessary -- recompute them as init_geometry does
-    {
-        const float g = (float)1.6180339887;
-        const float vert[12][3] = { { 0, 1, g }, { 0, -1, g }, { 0, 1, -g }, { 0, -1, -g },
-                                    { 1, g, 0 }, { -1, g, 0 }, { 1, -g, 0 }, { -1, -g, 0 },
-                                    { g, 0, 1 }, { -g, 0, 1 }, { g, 0, -1 }, { -g, 0, -1 } };
-        for (int v = 0; v < 12; v++) {
-            const float mag = sqrtf(vert[v][0] * vert[v][0] + vert[v][1] * vert[v][1] +
-                                    vert[v][2] * vert[v][2]);
-            for (int k = 0; k < 3; k++)
-                verts[3 * v + k] = vert[v][k] * 1.0f / mag;
+            cnt[id]++;
         }
     }
     for (int v = 0; v < 12; v++)
@@ -2821,24 +2818,33 @@ int sift3d_hip_set_mesh(const float *faces)
                            (binoff[idx[f * 3 + 2]] << 20);
         memcpy(f16 + f * 16 + 13, &packed, sizeof(int));
     }
+    // Octant table of icos_guess: the face that holds a point well inside each of the four
+    // regions of every sign octant, found with the reference's own acceptance test.
+    int oct[32];
+    {
+        const float g = 1.6180339887f;
+        const float rep[4][3] = { { 1.0f, 1.0f, 1.0f },
+                                  { g / 3.0f, 0.05f, (2.0f * g + 1.0f) / 3.0f },
+                                  { (2.0f * g + 1.0f) / 3.0f, g / 3.0f, 0.05f },
+                                  { 0.05f, (2.0f * g + 1.0f) / 3.0f, g / 3.0f } };
+        for (int c = 0; c < 4; c++)
+            for (int o = 0; o < 8; o++) {
+                const float r[3] = { (o & 1) ? -rep[c][0] : rep[c][0], (o & 2) ? -rep[c][1] : rep[c][1],
+                                     (o & 4) ? -rep[c][2] : rep[c][2] };
+                int hit = -1;
+                for (int f = 0; f < 20 && hit < 0; f++)
+                    if (host_face_pass(f16, f, r))
+                        hit = f;
+                if (hit < 0) {
+                    snprintf(g_err, sizeof(g_err), "sift3d_hip_set_mesh: no face holds a probe direction");
+                    return SIFT3D_FAILURE;
+                }
+                oct[c * 8 + o] = hit;
+            }
+    }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_bin_off), binoff, sizeof(binoff)));
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_face16), f16, sizeof(f16)));
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_face_idx), idx, sizeof(idx)));
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_verts), verts, sizeof(verts)));
-    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_vert_faces), vfaces, sizeof(vfaces)));
-    {
-        int vf5[12], vmask[12];
-        for (int v = 0; v < 12; v++) {
-            vf5[v] = 0;
-            vmask[v] = 0;
-            for (int k = 0; k < 5; k++) {
-                vf5[v] |= vfaces[v * 5 + k] << (5 * k);
-                vmask[v] |= 1 << vfaces[v * 5 + k];
-            }
-        }
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_vf5), vf5, sizeof(vf5)));
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_vmask), vmask, sizeof(vmask)));
-    }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_oct_face), oct, sizeof(oct)));
     return SIFT3D_SUCCESS;
 }
 
@@ -2847,11 +2853,16 @@ int sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d
 {
     if (!n)
         return SIFT3D_SUCCESS;
-    // diagnostic only (wrong results): 1 skips the ordered commit, 2 the whole batch -- used to
-    // attribute the kernel's time to scan / per-voxel terms / commit
+#ifdef SIFT3D_AMD_DIAG
+    // diagnostic build only (wrong results): 1 skips the commit, 2 the whole batch -- used by
+    // profiles/ scripts to attribute the kernel's time to scan / per-voxel terms / commit
     static int ablate = getenv("SIFT3D_AMD_DESC_ABLATE") ? atoi(getenv("SIFT3D_AMD_DESC_ABLATE")) : 0;
     hipLaunchKernelGGL(k_describe, dim3(n), dim3(64), 0, (hipStream_t)stream, d_levels, d_kp, n,
                        d_hist, ablate);
+#else
+    hipLaunchKernelGGL(k_describe, dim3(n), dim3(64), 0, (hipStream_t)stream, d_levels, d_kp, n,
+                       d_hist);
+#endif
     LAUNCH_CHECK();
     return SIFT3D_SUCCESS;
 }

@@ -3,9 +3,12 @@
   (2) the oracle (oracle/sift3d_oracle.c, itself pinned to those vectors) on seeded inputs.
 
 Bar (BASELINE.json north_star): bit-exact float32 pyramid, candidate counts, keypoint
-indices / scales / strengths; orientation and descriptor floats within 1e-5 relative
-(the tolerance is written next to each check; in practice both are bit-exact too because
-window sums are accumulated in the reference's order).
+indices / scales / strengths; orientation and descriptor floats within 1e-5 relative (the
+tolerance is written next to each check).  Orientation sums are accumulated in the
+reference's order, so R is in practice bit-exact (it feeds threshold decisions).  Descriptor
+histograms use every per-voxel value of the reference bit for bit but a different -- fixed,
+reproducible -- summation order (two half-wave partial histograms), so they agree to a few
+float ulps per element, checked ELEMENTWISE against 1e-5 (util.rel_err has no absolute term).
 """
 import json
 
@@ -292,8 +295,7 @@ def test_detect_describe_golden(gpu, oracle_mod, name):
     idx = g["desc_idx"]
     assert util.rel_err(m[idx, 3:], g["desc_hist"]) <= RTOL
     np.testing.assert_allclose(m[:, 3:].astype(np.float64).sum(1), g["desc_rowsum"], rtol=1e-5)
-    # in practice: bit-exact
-    assert np.mean(m[idx, 3:] == g["desc_hist"]) > 0.999
+    # R: in practice bit-exact (reference-order sums)
     assert np.mean(k["R"] == g["kp_R"]) > 0.999
     for lim in (0, 10):
         det2, kp2, rc = _run_api(api, vol, tuple(g["units"]), params)
@@ -332,7 +334,6 @@ def test_detect_describe_vs_oracle(gpu, oracle_mod, n, gen):
     assert o.describe() == 0
     m, om = desc.to_mat_rm(), o.desc_mat()
     assert util.rel_err(m, om) <= RTOL
-    assert np.mean(m == om) > 0.999
     # describe after sort+truncate (the CLI's order, cli/kpSift3D.c:122)
     kp.sort_by_strength(25)
     o.sort_by_strength(25)
@@ -434,9 +435,10 @@ def test_g5_512_golden(gpu, oracle_mod):
     m = desc.to_mat_rm()
     assert util.rel_err(m[idx, 3:], g["desc_hist_s"]) <= RTOL
     np.testing.assert_allclose(m[:, 3:].astype(np.float64).sum(1), g["desc_rowsum"], rtol=1e-5)
-    exact_D = util.digest(m[:, 3:]) == dig["desc_hist"]
-    # the contract is 1e-5; bit-exactness of R and of the descriptors is reported, not required
-    print("g5_512: R bit-exact: %s, descriptors bit-exact: %s" % (exact_R, exact_D))
+    # R is accumulated in the reference's order: the digest of all 42 501 matrices must match
+    assert exact_R, "R differs from the reference at 512^3"
+    print("g5_512: max elementwise relative descriptor error on the sampled rows: %.3g"
+          % util.rel_err(m[idx, 3:], g["desc_hist_s"]))
 
 
 def test_read_image_then_detect(gpu, oracle_mod, tmp_path):
