@@ -1744,7 +1744,7 @@ __constant__ int c_bin_off[12];    // LDS offset of each vertex's 64-cell block 
 // relative to the octant's central face: see icos_guess
 __constant__ int c_oct_face[32];
 
-constexpr int DQ = 128; // compaction queue length (power of two, >= 2 * 64)
+constexpr int DQ = 256; // compaction queue length (power of two, >= 63 + 2 * 64)
 // LDS histogram: bin (cell, vertex) lives at c_bin_off[vertex] + cell, cell = ix + 4*iy + 16*iz.
 // The offsets are 64*rank + {0, 8, 18, 26}[colour] for a proper 4-colouring of the
 // icosahedron's vertices, which puts the 24 bins of any voxel (8 neighbouring cells x the 3
@@ -1763,6 +1763,16 @@ constexpr int RROW = 36;
 #define DESC_ABLATE_ARG
 #define DESC_ABLATE(bit) false
 #endif
+
+// Lanes of ONE wave exchanging data through LDS: the DS operations of a wave execute in issue
+// order, so a read issued after a write sees it -- no s_waitcnt, no s_barrier; the fences only
+// keep the compiler from moving LDS accesses across the hand-over point.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // cart2bary + the acceptance test of icos_hist_bin (sift.c:276-297, 1268-1286) for one face,
 // the reference's float expressions.  fr: the face's 16-float record (LDS).
@@ -1815,6 +1825,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     __shared__ __attribute__((aligned(16))) float sface[20 * 16]; // c_face16 (per-lane face index)
     __shared__ int queue[DQ];     // xx | yy<<10 | zz<<20, window-relative, in scan order
     __shared__ int soct[32];      // c_oct_face
+    __shared__ uint64_t sexp[32]; // s3d_exp2_tab (per-lane index)
     const uint32_t ki = blockIdx.x;
     if (ki >= n)
         return;
@@ -1826,8 +1837,10 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
         hist[i] = 0.0f;
     for (int i = lane; i < 20 * 16; i += 64)
         sface[i] = c_face16[i];
-    if (lane < 32)
+    if (lane < 32) {
         soct[lane] = c_oct_face[lane];
+        sexp[lane] = s3d_exp2_tab[lane];
+    }
 
     const float sigma = (float)(K.sd * 7.071067812);                  // sift.c:1453
     const float rad = (float)(2.0 * (double)sigma);                   // sift.c:1454
@@ -1871,9 +1884,9 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
         vbx = (kx + half_w) * bin_f;                               // sift.c:1483-1485
         vby = (ky + half_w) * bin_f;
         vbz = (kz + half_w) * bin_f;
-        return !(sq > rad2) &&                                     // sift.c:106 (float)
-               !(vbx < 0 || vby < 0 || vbz < 0 || vbx >= 4.0f || vby >= 4.0f ||
-                 vbz >= 4.0f);                                     // sift.c:1488-1492
+        // sift.c:106 (float) and sift.c:1488-1492: none of vb* < 0, none >= 4 (finite inputs)
+        const float lo = fminf(fminf(vbx, vby), vbz), hi = fmaxf(fmaxf(vbx, vby), vbz);
+        return !(sq > rad2) && !(lo < 0.0f) && !(hi >= 4.0f);
     };
 
     // One batch: the next `cnt` (<= 64) queued voxels, in scan order.
@@ -1881,20 +1894,24 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     // their HBM/L2 latency overlaps the previous batch's binning and commit.
     float pv[7] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     int ppk = 0;
+    // level samples are read through a global-address-space pointer (the pointer comes out of a
+    // table in memory, which would otherwise make these flat loads); nx*ny < 2^31
+    typedef const float __attribute__((address_space(1))) *gfloat_p;
+    const gfloat_p gdata = (gfloat_p)L.data;
+    const uint32_t ys32 = (uint32_t)L.nx, zs32 = (uint32_t)L.nx * (uint32_t)L.ny;
     auto prefetch = [&](uint32_t start, int cnt) {
         if (lane < cnt) {
             ppk = queue[(start + lane) & (DQ - 1)];
             const int x = B.xs + (ppk & 1023), y = B.ys + ((ppk >> 10) & 1023),
                       zl = B.zs + (ppk >> 20) - L.z_off;
-            const size_t ys = L.nx, zs = (size_t)L.nx * L.ny;
-            const float *p = L.data + (size_t)x + ys * y + zs * zl;
-            pv[0] = p[1]; pv[1] = *(p - 1); pv[2] = p[ys]; pv[3] = *(p - ys);
-            pv[4] = p[zs]; pv[5] = *(p - zs);
+            const gfloat_p p = gdata + ((uint64_t)zs32 * (uint32_t)zl + (uint32_t)(x + (int)ys32 * y));
+            pv[0] = p[1]; pv[1] = *(p - 1); pv[2] = p[ys32]; pv[3] = *(p - ys32);
+            pv[4] = p[zs32]; pv[5] = *(p - zs32);
             // the Gaussian weight only needs the coordinates: it also flies one batch ahead
             const float dx = ((float)x - K.cx) * L.ux;                 // sift.c:102-104
             const float dy = ((float)y - K.cy) * L.uy;
             const float dz = ((float)(B.zs + (ppk >> 20)) - K.cz) * L.uz;
-            pv[6] = s3d_expf(-0.5f * (dx * dx + dy * dy + dz * dz) / sig2); // sift.c:1498
+            pv[6] = s3d_expf_with(-0.5f * (dx * dx + dy * dy + dz * dz) / sig2, sexp); // sift.c:1498
         }
     };
     auto batch = [&](int cnt, const float *cv, int pk) {
@@ -1989,13 +2006,15 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                     ab[j][l5] = abv[j];
                 }
             }
-            __syncthreads();
+            wave_sync();
             // Commit: round u adds voxel u of the half batch (half-wave 0) and voxel 16 + u
             // (half-wave 1), each into its half-wave's own histogram.  The 24 lanes of a voxel
             // own 24 distinct bins (8 cells x 3 face vertices), so the voxel's adds are ONE plain
             // LDS read-modify-write; the DS operations of a wave execute in issue order, so
-            // round u + 1 sees round u's sums.  Records of four rounds are read with three
-            // 16-byte loads, one chunk ahead.
+            // round u + 1 sees round u's sums.  (Reading round u + 1's bins before round u's sums
+            // are written is not an option: a bin of round u + 1 is usually a bin that ANOTHER
+            // lane writes in round u.)  Records of four rounds are read with three 16-byte
+            // loads, one chunk ahead.
             if (!DESC_ABLATE(1)) {
                 const int hb = half * 16;
                 int4 mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb]);
@@ -2018,7 +2037,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                     }
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
     };
 
@@ -2042,29 +2061,40 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
         const int ppl = pbx > 0 && pby > 0 ? pbx * pby : 0;
         const int ox = pxs - B.xs, oy = pys - B.ys;
         // (yy, xx) of this lane's voxel in the rectangle; a chunk of 64 voxels further it is
-        // (yy + q64, xx + r64), one more row if xx wraps
+        // (yy + q64, xx + r64), one more row if xx wraps.  Two chunks are tested per iteration
+        // (independent arithmetic: the second hides the latency of the first).
         const int q64 = pbx > 0 ? 64 / pbx : 0, r64 = pbx > 0 ? 64 - q64 * pbx : 0;
         int yy = pbx > 0 ? lane / pbx : 0, xx = pbx > 0 ? lane - yy * pbx : 0;
-        for (int c0 = 0; c0 < ppl; c0 += 64) {
+        for (int c0 = 0; c0 < ppl; c0 += 128) {
+            int xx1 = xx + r64, yy1 = yy + q64;
+            if (xx1 >= pbx) {
+                xx1 -= pbx;
+                yy1++;
+            }
             float sq, vbx, vby, vbz;
-            const bool in = window(pxs + xx, pys + yy, z, sq, vbx, vby, vbz) && c0 + lane < ppl;
-            const int pk = (ox + xx) | ((oy + yy) << 10) | ((z - B.zs) << 20);
-            xx += r64;
-            yy += q64;
+            const bool in0 = window(pxs + xx, pys + yy, z, sq, vbx, vby, vbz) && c0 + lane < ppl;
+            const bool in1 = window(pxs + xx1, pys + yy1, z, sq, vbx, vby, vbz) && c0 + 64 + lane < ppl;
+            const int pk0 = (ox + xx) | ((oy + yy) << 10) | ((z - B.zs) << 20);
+            const int pk1 = (ox + xx1) | ((oy + yy1) << 10) | ((z - B.zs) << 20);
+            xx = xx1 + r64;
+            yy = yy1 + q64;
             if (xx >= pbx) {
                 xx -= pbx;
                 yy++;
             }
-            const unsigned long long m = __ballot(in);
-            if (m == 0ull)
+            const unsigned long long m0 = __ballot(in0), m1 = __ballot(in1);
+            if ((m0 | m1) == 0ull)
                 continue;
-            if (in)
-                queue[(qtail + (uint32_t)__popcll(m & lt_mask)) & (DQ - 1)] = pk;
-            qtail += (uint32_t)__popcll(m);
-            __syncthreads();
+            const uint32_t n0 = (uint32_t)__popcll(m0);
+            if (in0)
+                queue[(qtail + (uint32_t)__popcll(m0 & lt_mask)) & (DQ - 1)] = pk0;
+            if (in1)
+                queue[(qtail + n0 + (uint32_t)__popcll(m1 & lt_mask)) & (DQ - 1)] = pk1;
+            qtail += n0 + (uint32_t)__popcll(m1);
+            wave_sync();
             // A full batch leaves the queue as soon as its samples are requested (its packed
             // coordinates travel in ppk), one batch ahead of its binning and commit
-            if (qtail - qhead >= 64) {
+            while (qtail - qhead >= 64) {
                 if (pend) {
                     float cv[7];
 #pragma unroll
@@ -2104,7 +2134,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
             batch(cnt, cv, cpk);
         }
     }
-    __syncthreads();
+    wave_sync();
     // The two half-wave histograms are merged in a fixed order, then normalize_desc -> clamp ->
     // normalize_desc (sift.c:1402-1429, 1514-1526).  The reference sums the 768 squares in
     // double in element order; here every lane sums its 12-13 slots and the 64 partial sums are
@@ -2112,7 +2142,7 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     const float trunc = 0.2f * 128.0f / 768.0f;                               // sift.c:45
     for (int i = lane; i < HIST_LDS; i += 64)
         hist[i] = hist[i] + hist[HIST_LDS + i];
-    __syncthreads();
+    wave_sync();
     for (int pass = 0; pass < 2; pass++) {
         double norm = 0.0;
         for (int i = lane; i < HIST_LDS; i += 64) {
@@ -2124,14 +2154,14 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
             norm += __shfl_xor(norm, o, 64);
         norm = sqrt(norm) + 2.220446049250313e-16;                            // DBL_EPSILON
         const float inv = (float)(1.0 / norm);                                // 1.0f / norm
-        __syncthreads();
+        wave_sync();
         for (int i = lane; i < HIST_LDS; i += 64) {
             float el = hist[i] * inv;
             if (pass == 0)
                 el = el < trunc ? el : trunc;                                 // sift.c:1520
             hist[i] = el;
         }
-        __syncthreads();
+        wave_sync();
     }
     for (int i = lane; i < 768; i += 64)
         out[(size_t)orow * 768 + i] = hist[c_bin_off[i % 12] + i / 12];
