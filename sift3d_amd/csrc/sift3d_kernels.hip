@@ -1751,7 +1751,7 @@ constexpr int DQ = 256; // compaction queue length (power of two, >= 63 + 2 * 64
 // vertices of a face) on 24 different banks of the 32 that ds_read_b32/ds_write_b32 use.
 constexpr int HIST_LDS = 800;
 // Phase A -> phase B records, field-major: row f holds field f of half a batch (32 voxels; the
-// records go through LDS half a batch at a time, which keeps a fourth wave per SIMD resident).
+// records go through LDS half a batch at a time: LDS capacity is what limits the waves per CU).
 // Rows are 36 floats apart: the eight rows that the 24 committer lanes of a half-wave read with
 // ds_read_b128 (four voxels at a time) fall on disjoint bank quads.
 constexpr int RROW = 36;
@@ -1810,37 +1810,50 @@ __device__ __forceinline__ int icos_guess(float rx, float ry, float rz)
     const float t1 = ax + g2 * ay - g * az;      // edge (0,1,g)-(g,0,1), beyond: face with (0,-1,g)
     const float t2 = ay + g2 * az - g * ax;      // edge (g,0,1)-(1,g,0), beyond: face with (g,0,-1)
     const float t3 = az + g2 * ax - g * ay;      // edge (1,g,0)-(0,1,g), beyond: face with (-1,g,0)
-    const int cls = t1 < 0.0f ? 1 : (t2 < 0.0f ? 2 : (t3 < 0.0f ? 3 : 0));
-    return cls * 8 + (rx < 0.0f ? 1 : 0) + (ry < 0.0f ? 2 : 0) + (rz < 0.0f ? 4 : 0);
+    // (integer arithmetic, not nested selects: the compiler turns those into branches, and the
+    // caller wants this in one basic block with the commit chain)
+    const int n1 = t1 < 0.0f, n2 = t2 < 0.0f, n3 = t3 < 0.0f;
+    const int cls = n1 + (1 - n1) * (2 * n2 + (1 - n2) * 3 * n3);
+    return cls * 8 + (int)(rx < 0.0f) + 2 * (int)(ry < 0.0f) + 4 * (int)(rz < 0.0f);
 }
 
-__global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restrict__ levels,
+constexpr int DWAVES = 4;   // keypoints (waves) per workgroup; they share the read-only tables
+
+__global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level *__restrict__ levels,
                                                  const sift3d_hip_kp *__restrict__ kps, uint32_t n,
                                                  float *__restrict__ out DESC_ABLATE_ARG)
 {
-    __shared__ float hist[2 * HIST_LDS];   // one private histogram per half-wave
-    __shared__ __attribute__((aligned(16))) float mw[8][RROW]; // mag * trilinear weight of the eight cells
-    __shared__ __attribute__((aligned(16))) float bw[3][RROW]; // barycentric weights
-    __shared__ __attribute__((aligned(16))) int ab[3][RROW];   // byte address of bin (base cell, face vertex j)
+    // per wave: 2 * 3200 + 2016 + 1024 B; per workgroup 39.4 KB -> four workgroups = 16 waves per CU
+    __shared__ float hist_[DWAVES][2 * HIST_LDS];   // one private histogram per half-wave
+    __shared__ __attribute__((aligned(16))) float mw_[DWAVES][8][RROW]; // mag * trilinear weight of the eight cells
+    __shared__ __attribute__((aligned(16))) float bw_[DWAVES][3][RROW]; // barycentric weights
+    __shared__ __attribute__((aligned(16))) int ab_[DWAVES][3][RROW];   // byte address of bin (base cell, face vertex j)
+    __shared__ int queue_[DWAVES][DQ];   // xx | yy<<10 | zz<<20, window-relative, in scan order
     __shared__ __attribute__((aligned(16))) float sface[20 * 16]; // c_face16 (per-lane face index)
-    __shared__ int queue[DQ];     // xx | yy<<10 | zz<<20, window-relative, in scan order
     __shared__ int soct[32];      // c_oct_face
     __shared__ uint64_t sexp[32]; // s3d_exp2_tab (per-lane index)
-    const uint32_t ki = blockIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    float *const hist = hist_[wv];
+    float(*const mw)[RROW] = mw_[wv];
+    float(*const bw)[RROW] = bw_[wv];
+    int(*const ab)[RROW] = ab_[wv];
+    int *const queue = queue_[wv];
+    for (int i = threadIdx.x; i < 20 * 16; i += 64 * DWAVES)
+        sface[i] = c_face16[i];
+    if (threadIdx.x < 32) {
+        soct[threadIdx.x] = c_oct_face[threadIdx.x];
+        sexp[threadIdx.x] = s3d_exp2_tab[threadIdx.x];
+    }
+    for (int i = lane; i < 2 * HIST_LDS; i += 64)
+        hist[i] = 0.0f;
+    __syncthreads();              // the only workgroup barrier: from here on the waves are independent
+    const uint32_t ki = blockIdx.x * DWAVES + wv;
     if (ki >= n)
         return;
-    const int lane = threadIdx.x;
     const sift3d_hip_kp K = kps[ki];
     const sift3d_hip_level L = levels[K.level];
     const uint32_t orow = K.row1 ? K.row1 - 1 : ki;   // output row (launch order may differ)
-    for (int i = lane; i < 2 * HIST_LDS; i += 64)
-        hist[i] = 0.0f;
-    for (int i = lane; i < 20 * 16; i += 64)
-        sface[i] = c_face16[i];
-    if (lane < 32) {
-        soct[lane] = c_oct_face[lane];
-        sexp[lane] = s3d_exp2_tab[lane];
-    }
 
     const float sigma = (float)(K.sd * 7.071067812);                  // sift.c:1453
     const float rad = (float)(2.0 * (double)sigma);                   // sift.c:1454
@@ -1865,7 +1878,6 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     // byte offset of this lane's cell corner, in this half-wave's histogram
     const int coff4 = 4 * (pdx + 4 * pdy + 16 * pdz) + half * (HIST_LDS * 4);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    __syncthreads();
 
     uint32_t qhead = 0, qtail = 0; // wave-uniform
     bool pend = false;             // registers pv/ppk hold the batch starting at qhead
@@ -1899,146 +1911,179 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
     typedef const float __attribute__((address_space(1))) *gfloat_p;
     const gfloat_p gdata = (gfloat_p)L.data;
     const uint32_t ys32 = (uint32_t)L.nx, zs32 = (uint32_t)L.nx * (uint32_t)L.ny;
+    // Sample requests of a batch, branch-free: lanes beyond cnt keep their previous (valid) voxel
+    // and simply fetch it again.  The Gaussian weight (prefetch_weight) only needs the
+    // coordinates; it is evaluated later, inside the commit chain of the previous batch.
+    auto prefetch_loads = [&](uint32_t start, int cnt) {
+        const int qv = queue[(start + lane) & (DQ - 1)];
+        ppk = lane < cnt ? qv : ppk;
+        const int x = B.xs + (ppk & 1023), y = B.ys + ((ppk >> 10) & 1023),
+                  zl = B.zs + (ppk >> 20) - L.z_off;
+        const gfloat_p p = gdata + ((uint64_t)zs32 * (uint32_t)zl + (uint32_t)(x + (int)ys32 * y));
+        pv[0] = p[1]; pv[1] = *(p - 1); pv[2] = p[ys32]; pv[3] = *(p - ys32);
+        pv[4] = p[zs32]; pv[5] = *(p - zs32);
+    };
+    auto prefetch_weight = [&]() {
+        const int x = B.xs + (ppk & 1023), y = B.ys + ((ppk >> 10) & 1023);
+        const float dx = ((float)x - K.cx) * L.ux;                 // sift.c:102-104
+        const float dy = ((float)y - K.cy) * L.uy;
+        const float dz = ((float)(B.zs + (ppk >> 20)) - K.cz) * L.uz;
+        // (queued voxels passed the window test: the argument lies in [-2, 0])
+        pv[6] = s3d_expf_in_range(-0.5f * (dx * dx + dy * dy + dz * dz) / sig2, sexp); // sift.c:1498
+    };
     auto prefetch = [&](uint32_t start, int cnt) {
-        if (lane < cnt) {
-            ppk = queue[(start + lane) & (DQ - 1)];
-            const int x = B.xs + (ppk & 1023), y = B.ys + ((ppk >> 10) & 1023),
-                      zl = B.zs + (ppk >> 20) - L.z_off;
-            const gfloat_p p = gdata + ((uint64_t)zs32 * (uint32_t)zl + (uint32_t)(x + (int)ys32 * y));
-            pv[0] = p[1]; pv[1] = *(p - 1); pv[2] = p[ys32]; pv[3] = *(p - ys32);
-            pv[4] = p[zs32]; pv[5] = *(p - zs32);
-            // the Gaussian weight only needs the coordinates: it also flies one batch ahead
-            const float dx = ((float)x - K.cx) * L.ux;                 // sift.c:102-104
-            const float dy = ((float)y - K.cy) * L.uy;
-            const float dz = ((float)(B.zs + (ppk >> 20)) - K.cz) * L.uz;
-            pv[6] = s3d_expf_with(-0.5f * (dx * dx + dy * dy + dz * dz) / sig2, sexp); // sift.c:1498
+        prefetch_loads(start, cnt);
+        prefetch_weight();
+    };
+
+    // Records of the batch that is being committed, one voxel per lane: mag * trilinear weight
+    // of the eight cells, the three barycentric weights, the three bin addresses.  Empty records
+    // (zero weight, bin address 0) add 0 to a valid bin.
+    float rmw[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, rbw[3] = { 0.f, 0.f, 0.f };
+    int rab[3] = { 0, 0, 0 };
+    // One commit pass: the records of half a batch (voxels 32 * pass .. 32 * pass + 31) go to
+    // LDS, field-major, then round u adds voxel u of them (half-wave 0) and voxel 16 + u
+    // (half-wave 1), each into its half-wave's own histogram.  The 24 lanes of a voxel own 24
+    // distinct bins (8 cells x 3 face vertices), so the voxel's adds are ONE plain LDS
+    // read-modify-write; the DS operations of a wave execute in issue order, so round u + 1
+    // sees round u's sums.  (Reading round u + 1's bins before round u's sums are written is
+    // not an option: a bin of round u + 1 is usually a bin that ANOTHER lane writes in round
+    // u.)  The chain of dependent LDS round trips is the longest latency of the kernel and needs
+    // almost no VALU, so each pass is issued in one basic block with half of the arithmetic of
+    // the NEXT batch (see batch()), which the scheduler interleaves with it.  Records of four
+    // rounds are read with three 16-byte loads, one chunk ahead.
+    auto commit_write = [&](int pass) {
+        if (half == pass) {
+#pragma unroll
+            for (int c = 0; c < 8; c++)
+                mw[c][l5] = rmw[c];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                bw[j][l5] = rbw[j];
+                ab[j][l5] = rab[j];
+            }
+        }
+        wave_sync();
+    };
+    auto commit_rounds = [&]() {
+        if (DESC_ABLATE(1)) return;
+        const int hb = half * 16;
+        int4 mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb]);
+        float4 mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb]);
+        float4 bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int mb[4] = { mb4.x, mb4.y, mb4.z, mb4.w };
+            const float mv[4] = { mw4.x, mw4.y, mw4.z, mw4.w }, bv[4] = { bw4.x, bw4.y, bw4.z, bw4.w };
+            if (c < 3) {
+                mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb + 4 * c + 4]);
+                mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb + 4 * c + 4]);
+                bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb + 4 * c + 4]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float *bin = reinterpret_cast<float *>(reinterpret_cast<char *>(hist) + (mb[u] + coff4));
+                const float val = mv[u] * bv[u];                               // sift.c:1371-1373
+                *bin = *bin + val;
+            }
         }
     };
-    auto batch = [&](int cnt, const float *cv, int pk) {
-        float mwv[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, bwv[3] = { 0.f, 0.f, 0.f };
-        int abv[3] = { 0, 0, 0 };
-        if (DESC_ABLATE(2)) return;
-        {
-            // (lanes beyond cnt compute on stale coordinates and are discarded below)
-            const int x = B.xs + (pk & 1023), y = B.ys + ((pk >> 10) & 1023), z = B.zs + (pk >> 20);
-            float sq, vbx, vby, vbz;
-            window(x, y, z, sq, vbx, vby, vbz);
-            // IM_GET_GRAD_ISO (sift.c:140-145, immacros.h:105-111)
-            float gx = 0.5f * (cv[0] - cv[1]), gy = 0.5f * (cv[2] - cv[3]), gz = 0.5f * (cv[4] - cv[5]);
-            gx *= iux;
-            gy *= iuy;
-            gz *= iuz;
-            const float w = cv[6];                                 // sift.c:1498, see prefetch
-            gx = gx * w; gy = gy * w; gz = gz * w;
-            const float rx = R[0] * gx + R[3] * gy + R[6] * gz;    // sift.c:1502
-            const float ry = R[1] * gx + R[4] * gy + R[7] * gz;
-            const float rz = R[2] * gx + R[5] * gy + R[8] * gz;
-            const float m2 = rx * rx + ry * ry + rz * rz;
-            const bool live = lane < cnt && !(m2 < 1.1920928955078125e-06f);   // sift.c:1264
-            // icos_hist_bin (sift.c:1268-1286): the first face in table order whose barycentrics
-            // are >= -eps wins.  A face other than the one the ray really crosses can only pass
-            // if the ray misses it by ~eps, i.e. if the ray is within ~eps of an edge of its own
-            // face.  So: guess the face, evaluate it with cart2bary's arithmetic, and accept it
-            // when it passes with all barycentrics > 2e-5 (then every other face fails by a wide
-            // margin and the first match is unique); anything else -- ~1e-4 of the voxels --
-            // takes the reference's scan over all 20 faces.
-            int fidx = 0;
-            float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-            const int f0 = soct[icos_guess(rx, ry, rz)];
-            bool found = face_eval(reinterpret_cast<const float4 *>(sface) + f0 * 4, rx, ry, rz, b0, b1,
-                                   b2, fidx) &&
-                         fminf(b0, fminf(b1, b2)) > 2e-5f;
-            if (__builtin_expect(__ballot(live && !found) != 0ull, 0)) {
-                bool open = live && !found;
+    // One batch: phase A of `cnt` (<= 64) voxels whose samples were fetched one batch ago (cv,
+    // pk), overlapped with the two commit passes of the previous batch (records in rmw/rbw/rab)
+    // and with the sample requests of the next one (ncnt voxels from queue position nstart;
+    // ncnt may be 0); then this batch's records take the previous one's place.
+    auto batch = [&](int cnt, const float *cv, int pk, uint32_t nstart, int ncnt) {
+        prefetch_loads(nstart, ncnt);
+        if (DESC_ABLATE(2)) { prefetch_weight(); return; }
+        commit_write(0);
+        // ---- basic block 1: commit rounds of voxels 0..31  ||  window, gradient, face
+        commit_rounds();
+        // (lanes beyond cnt compute on stale -- finite -- values and are discarded below)
+        const int x = B.xs + (pk & 1023), y = B.ys + ((pk >> 10) & 1023), z = B.zs + (pk >> 20);
+        float sq, vbx, vby, vbz;
+        window(x, y, z, sq, vbx, vby, vbz);
+        // IM_GET_GRAD_ISO (sift.c:140-145, immacros.h:105-111)
+        float gx = 0.5f * (cv[0] - cv[1]), gy = 0.5f * (cv[2] - cv[3]), gz = 0.5f * (cv[4] - cv[5]);
+        gx *= iux;
+        gy *= iuy;
+        gz *= iuz;
+        const float w = cv[6];                                 // sift.c:1498, see prefetch_weight
+        gx = gx * w; gy = gy * w; gz = gz * w;
+        const float rx = R[0] * gx + R[3] * gy + R[6] * gz;    // sift.c:1502
+        const float ry = R[1] * gx + R[4] * gy + R[7] * gz;
+        const float rz = R[2] * gx + R[5] * gy + R[8] * gz;
+        const float m2 = rx * rx + ry * ry + rz * rz;
+        const bool live = lane < cnt && !(m2 < 1.1920928955078125e-06f);   // sift.c:1264
+        // icos_hist_bin (sift.c:1268-1286): the first face in table order whose barycentrics
+        // are >= -eps wins.  A face other than the one the ray really crosses can only pass
+        // if the ray misses it by ~eps, i.e. if the ray is within ~eps of an edge of its own
+        // face.  So: guess the face, evaluate it with cart2bary's arithmetic, and accept it
+        // when it passes with all barycentrics > 2e-5 (then every other face fails by a wide
+        // margin and the first match is unique); anything else -- ~1e-4 of the voxels --
+        // takes the reference's scan over all 20 faces.
+        int fidx = 0;
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        const int f0 = soct[icos_guess(rx, ry, rz)];
+        bool found = face_eval(reinterpret_cast<const float4 *>(sface) + f0 * 4, rx, ry, rz, b0, b1,
+                               b2, fidx) &&
+                     fminf(b0, fminf(b1, b2)) > 2e-5f;
+        commit_write(1);
+        // ---- basic block 2: commit rounds of voxels 32..63  ||  cell weights, next batch's
+        // Gaussian weights
+        commit_rounds();
+        prefetch_weight();
+        // trilinear cell weights (sift.c:1318-1320, 1361-1363): weight = wx * wy * wz,
+        // value = mag * weight * bary.  A corner beyond the last cell is skipped by the
+        // reference (sift.c:1349-1352).  The commit below is free of predication -- all 24 lanes
+        // of a voxel always read-modify-write -- so the 2x2x2 block of cells is shifted to stay
+        // inside the grid instead: on an axis where the base cell is the last one (index 3) the
+        // block covers cells {2, 3}, cell 3 keeps its weight 1 - f and cell 2 gets weight 0.
+        // The 24 bins stay distinct and valid; adding mag * 0 * bary = +-0 changes nothing.
+        const float mag = sqrtf(m2);                           // sift.c:1331
+        const float fx = vbx - floorf(vbx);
+        const float fy = vby - floorf(vby);
+        const float fz = vbz - floorf(vbz);
+        const int ix = (int)vbx, iy = (int)vby, iz = (int)vbz;
+        const bool lx = ix >= 3, ly = iy >= 3, lz = iz >= 3;
+        const float ax[2] = { lx ? 0.0f : 1.0f - fx, lx ? 1.0f - fx : fx },
+                    ay[2] = { ly ? 0.0f : 1.0f - fy, ly ? 1.0f - fy : fy },
+                    az[2] = { lz ? 0.0f : 1.0f - fz, lz ? 1.0f - fz : fz };
+        float mwv[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float wt = ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1];
+            mwv[c] = mag * wt;
+        }
+        // (stale lanes may hold any coordinates: keep their cell inside the grid as well)
+        const int cell4 = 4 * (min(max(ix, 0), 2) + 4 * min(max(iy, 0), 2) + 16 * min(max(iz, 0), 2));
+        if (__builtin_expect(__ballot(live && !found) != 0ull, 0)) {
+            bool open = live && !found;
 #pragma unroll 1
-                for (int f = 0; f < 20; f++) {
-                    float xb, yb, zb;
-                    int fi;
-                    const bool hit = face_eval(reinterpret_cast<const float4 *>(sface) + f * 4, rx,
-                                               ry, rz, xb, yb, zb, fi);
-                    if (open && hit) {
-                        b0 = xb; b1 = yb; b2 = zb; fidx = fi;
-                        found = true;
-                        open = false;
-                    }
-                    if (__ballot(open) == 0ull)
-                        break;
+            for (int f = 0; f < 20; f++) {
+                float xb, yb, zb;
+                int fi;
+                const bool hit = face_eval(reinterpret_cast<const float4 *>(sface) + f * 4, rx,
+                                           ry, rz, xb, yb, zb, fi);
+                if (open && hit) {
+                    b0 = xb; b1 = yb; b2 = zb; fidx = fi;
+                    found = true;
+                    open = false;
                 }
-            }
-            if (live && found) {
-                const float mag = sqrtf(m2);                   // sift.c:1331
-                const float fx = vbx - floorf(vbx);            // sift.c:1318-1320
-                const float fy = vby - floorf(vby);
-                const float fz = vbz - floorf(vbz);
-                // A corner beyond the last cell is skipped by the reference (sift.c:1349-1352);
-                // here its weight is forced to 0: adding mag * 0 * bary = +-0 does not change a
-                // bin.
-                const int ix = (int)vbx, iy = (int)vby, iz = (int)vbz;
-                const float ax[2] = { 1.0f - fx, ix < 3 ? fx : 0.0f },
-                            ay[2] = { 1.0f - fy, iy < 3 ? fy : 0.0f },
-                            az[2] = { 1.0f - fz, iz < 3 ? fz : 0.0f };
-#pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    // weight = wx * wy * wz (sift.c:1361-1363); value = mag * weight * bary
-                    const float wt = ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1];
-                    mwv[c] = mag * wt;
-                }
-                bwv[0] = b0; bwv[1] = b1; bwv[2] = b2;
-                // byte addresses of the bins (base cell, face vertex j) -- the vertices
-                // addressed through the UNSWAPPED idx[] of the face (quirk Q1)
-                const int cell4 = 4 * (ix + 4 * iy + 16 * iz);
-#pragma unroll
-                for (int j = 0; j < 3; j++)
-                    abv[j] = 4 * ((fidx >> (10 * j)) & 1023) + cell4;
+                if (__ballot(open) == 0ull)
+                    break;
             }
         }
-        // Records go through LDS half a batch at a time.  Voxels without a contribution carry
-        // zero weights and bin address 0: the commit adds 0 to a valid bin for them.
-#pragma unroll 1
-        for (int hb2 = 0; hb2 < 2; hb2++) {
-            if (half == hb2) {
+        // this batch's records (voxels without a contribution: zero weights, bin address 0)
+        const bool ok = live && found;
 #pragma unroll
-                for (int c = 0; c < 8; c++)
-                    mw[c][l5] = mwv[c];
+        for (int c = 0; c < 8; c++)
+            rmw[c] = ok ? mwv[c] : 0.0f;
+        rbw[0] = ok ? b0 : 0.0f; rbw[1] = ok ? b1 : 0.0f; rbw[2] = ok ? b2 : 0.0f;   // (0 * NaN would be NaN)
+        // byte addresses of the bins (base cell, face vertex j) -- the vertices addressed
+        // through the UNSWAPPED idx[] of the face (quirk Q1)
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    bw[j][l5] = bwv[j];
-                    ab[j][l5] = abv[j];
-                }
-            }
-            wave_sync();
-            // Commit: round u adds voxel u of the half batch (half-wave 0) and voxel 16 + u
-            // (half-wave 1), each into its half-wave's own histogram.  The 24 lanes of a voxel
-            // own 24 distinct bins (8 cells x 3 face vertices), so the voxel's adds are ONE plain
-            // LDS read-modify-write; the DS operations of a wave execute in issue order, so
-            // round u + 1 sees round u's sums.  (Reading round u + 1's bins before round u's sums
-            // are written is not an option: a bin of round u + 1 is usually a bin that ANOTHER
-            // lane writes in round u.)  Records of four rounds are read with three 16-byte
-            // loads, one chunk ahead.
-            if (!DESC_ABLATE(1)) {
-                const int hb = half * 16;
-                int4 mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb]);
-                float4 mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb]);
-                float4 bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb]);
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int mb[4] = { mb4.x, mb4.y, mb4.z, mb4.w };
-                    const float mv[4] = { mw4.x, mw4.y, mw4.z, mw4.w }, bv[4] = { bw4.x, bw4.y, bw4.z, bw4.w };
-                    if (c < 3) {
-                        mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb + 4 * c + 4]);
-                        mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb + 4 * c + 4]);
-                        bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb + 4 * c + 4]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        float *bin = reinterpret_cast<float *>(reinterpret_cast<char *>(hist) + (mb[u] + coff4));
-                        const float val = mv[u] * bv[u];                               // sift.c:1371-1373
-                        *bin = *bin + val;
-                    }
-                }
-            }
-            wave_sync();
-        }
+        for (int j = 0; j < 3; j++)
+            rab[j] = ok ? 4 * ((fidx >> (10 * j)) & 1023) + cell4 : 0;
     };
 
     // The reference scans the whole bounding box of the sphere (sift.c:96-108).  Every voxel
@@ -2101,39 +2146,38 @@ __global__ __launch_bounds__(64) void k_describe(const sift3d_hip_level *__restr
                     for (int k = 0; k < 7; k++)
                         cv[k] = pv[k];
                     const int cpk = ppk;
-                    prefetch(qhead, 64);           // next batch's loads fly during this one
-                    qhead += 64;
-                    batch(64, cv, cpk);
+                    batch(64, cv, cpk, qhead, 64);  // the next batch's loads fly during this one
                 } else {
                     prefetch(qhead, 64);
-                    qhead += 64;
                     pend = true;
                 }
+                qhead += 64;
             }
         }
     }
     {
         int have = pend ? 64 : 0, rest = (int)(qtail - qhead);
-        while (have || rest) {
-            if (!have) {
-                prefetch(qhead, rest);
-                have = rest;
-                rest = 0;
-            }
+        if (!have && rest) {
+            prefetch(qhead, rest);
+            have = rest;
+            rest = 0;
+        }
+        while (have) {
             float cv[7];
 #pragma unroll
             for (int k = 0; k < 7; k++)
                 cv[k] = pv[k];
             const int cpk = ppk, cnt = have;
-            have = 0;
-            if (rest) {
-                prefetch(qhead, rest);
-                have = rest;
-                rest = 0;
-            }
-            batch(cnt, cv, cpk);
+            batch(cnt, cv, cpk, qhead, rest);
+            have = rest;
+            rest = 0;
         }
     }
+    // the last batch
+    commit_write(0);
+    commit_rounds();
+    commit_write(1);
+    commit_rounds();
     wave_sync();
     // The two half-wave histograms are merged in a fixed order, then normalize_desc -> clamp ->
     // normalize_desc (sift.c:1402-1429, 1514-1526).  The reference sums the 768 squares in
@@ -2887,11 +2931,11 @@ int sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d
     // diagnostic build only (wrong results): 1 skips the commit, 2 the whole batch -- used by
     // profiles/ scripts to attribute the kernel's time to scan / per-voxel terms / commit
     static int ablate = getenv("SIFT3D_AMD_DESC_ABLATE") ? atoi(getenv("SIFT3D_AMD_DESC_ABLATE")) : 0;
-    hipLaunchKernelGGL(k_describe, dim3(n), dim3(64), 0, (hipStream_t)stream, d_levels, d_kp, n,
-                       d_hist, ablate);
+    hipLaunchKernelGGL(k_describe, dim3((n + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
+                       (hipStream_t)stream, d_levels, d_kp, n, d_hist, ablate);
 #else
-    hipLaunchKernelGGL(k_describe, dim3(n), dim3(64), 0, (hipStream_t)stream, d_levels, d_kp, n,
-                       d_hist);
+    hipLaunchKernelGGL(k_describe, dim3((n + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
+                       (hipStream_t)stream, d_levels, d_kp, n, d_hist);
 #endif
     LAUNCH_CHECK();
     return SIFT3D_SUCCESS;

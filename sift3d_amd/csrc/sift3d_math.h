@@ -68,7 +68,8 @@ S3D_HD uint64_t s3d_f64_as_u64(double d)
  * limits (0 / +inf) are returned without libm's errno/fenv side effects.
  * `use_fma` selects the contraction pattern of glibc's FMA-enabled build
  * (what an x86-64 host with FMA3 dispatches to). */
-S3D_HD float s3d_expf_tab(float x, int use_fma, const uint64_t *tab)
+/* the table path itself: valid for -150 <= x <= 88.72 (branch-free) */
+S3D_HD float s3d_expf_core(float x, int use_fma, const uint64_t *tab)
 {
     const double inv_ln2_n = 0x1.71547652b82fep+0 * 32.0;
     const double shift = 0x1.8p+52;
@@ -78,10 +79,6 @@ S3D_HD float s3d_expf_tab(float x, int use_fma, const uint64_t *tab)
     double xd, z, kd, r, r2, y, s;
     uint64_t ki, t;
 
-    if (!(x >= -150.0f))
-        return x != x ? x : 0.0f;
-    if (x > 0x1.62e42ep6f)
-        return INFINITY;
     xd = (double)x;
     z = inv_ln2_n * xd;
     kd = z + shift;
@@ -106,6 +103,15 @@ S3D_HD float s3d_expf_tab(float x, int use_fma, const uint64_t *tab)
     return (float)y;
 }
 
+S3D_HD float s3d_expf_tab(float x, int use_fma, const uint64_t *tab)
+{
+    if (!(x >= -150.0f))
+        return x != x ? x : 0.0f;
+    if (x > 0x1.62e42ep6f)
+        return INFINITY;
+    return s3d_expf_core(x, use_fma, tab);
+}
+
 S3D_HD float s3d_expf_impl(float x, int use_fma) { return s3d_expf_tab(x, use_fma, s3d_exp2_tab); }
 
 #ifndef S3D_EXPF_FMA
@@ -116,6 +122,8 @@ S3D_HD float s3d_expf(float x) { return s3d_expf_impl(x, S3D_EXPF_FMA); }
 
 /* same, with the caller's copy of s3d_exp2_tab (the kernels keep one in LDS) */
 S3D_HD float s3d_expf_with(float x, const uint64_t *tab) { return s3d_expf_tab(x, S3D_EXPF_FMA, tab); }
+/* the caller guarantees -150 <= x <= 88.72: no range branches */
+S3D_HD float s3d_expf_in_range(float x, const uint64_t *tab) { return s3d_expf_core(x, S3D_EXPF_FMA, tab); }
 
 /* 3x3 symmetric eigen-decomposition, upper triangle of row-major A is read.
  * L ascending; eigenvector j is column j of row-major Q. */
