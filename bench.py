@@ -10,6 +10,9 @@ HBM when the timed region starts.  N = 1: the 512^3 volume BASELINE.json's metri
 on (configs[2]).  N > 1: every rank owns one Z-slab of 512 planes of a 512 x 512 x (512 N)
 volume (weak scaling; halo exchange + keypoint gather over RCCL, sift3d_amd/sharded.py).
 
+    python bench.py --gpus N --strong 1024 ...                # BASELINE configs[3]: ONE 1024^3 volume
+                                                              # as N Z-slabs (strong scaling)
+
 Rank 0 prints ONE JSON line: metric/value (Mvoxel/s, whole job), ms_per_step, plus
   roofline     the dominant pyramid kernel: algorithmic bytes per launch (8 B/voxel per 1-D
                pass) / its average launch time measured here with HIP events,
@@ -115,15 +118,44 @@ def kernel_microbench(torch, hip, n, reps=10):
     return out
 
 
-def cpu_baseline(budget_n=128):
-    """The reference's CPU path on a bounded sample of the same kind of volume."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _set_omp_threads(k):
+    """libgomp reads OMP_NUM_THREADS once; later changes go through omp_set_num_threads."""
+    import ctypes
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(k))
+        return True
+    except OSError:
+        return False
+
+
+def cpu_baseline(n_all=128, n_one=96):
+    """The reference's CPU path on bounded samples of the same kind of volume: once on this
+    GPU's share of the host cores, once on ONE thread (SURVEY.md 8d asks for both)."""
     threads = int(os.environ.get("OMP_NUM_THREADS", CPU_THREADS))
     from oracle import sift3d_oracle as so
-    vol = so.synth_lattice(budget_n, seed=11)
     ref_lib = os.path.join(ROOT, "oracle", "_ref", "libsift3d_refprobe.so")
+    kind = "port"
     if os.path.exists(ref_lib):
         try:
             from oracle import refprobe
+            refprobe.Probe().close()
+            kind = "reference"
+        except Exception as e:  # the reference build did not load on this host
+            sys.stderr.write("cpu_baseline: reference unavailable (%s), using the port\n" % e)
+
+    def run(n):
+        vol = so.synth_lattice(n, seed=11)
+        if kind == "reference":
             p = refprobe.Probe()
             t0 = time.time()
             assert p.detect_public(vol) == 0
@@ -132,24 +164,44 @@ def cpu_baseline(budget_n=128):
             t2 = time.time()
             nkp = len(p.keypoints()["strength"])
             p.close()
-            return dict(value=round(budget_n ** 3 / 1e6 / (t2 - t0), 4), unit="Mvoxel/s",
-                        cores=threads, kind="reference",
-                        sample="%d^3 lattice volume (1/%d of the workload's voxels), unmodified "
-                               "reference libsift3D (OpenMP): detect %.2f s + describe %.2f s, "
-                               "%d keypoints" % (budget_n, (512 // budget_n) ** 3, t1 - t0,
-                                                 t2 - t1, nkp))
-        except Exception as e:  # the reference build did not load on this host
-            sys.stderr.write("cpu_baseline: reference unavailable (%s), using the port\n" % e)
-    o = so.Oracle()
-    t0 = time.time()
-    assert o.detect(vol) == 0
-    t1 = time.time()
-    assert o.describe() == 0
-    t2 = time.time()
-    return dict(value=round(budget_n ** 3 / 1e6 / (t2 - t0), 4), unit="Mvoxel/s", cores=threads,
-                kind="port",
-                sample="%d^3 lattice volume, oracle restatement (OpenMP): detect %.2f s + describe "
-                       "%.2f s, %d keypoints" % (budget_n, t1 - t0, t2 - t1, len(o.keypoints())))
+        else:
+            o = so.Oracle()
+            t0 = time.time()
+            assert o.detect(vol) == 0
+            t1 = time.time()
+            assert o.describe() == 0
+            t2 = time.time()
+            nkp = len(o.keypoints())
+        return n ** 3 / 1e6 / (t2 - t0), t1 - t0, t2 - t1, nkp
+
+    v_all, d_all, e_all, k_all = run(n_all)
+    one = None
+    if _set_omp_threads(1):
+        v_one, d_one, e_one, k_one = run(n_one)
+        _set_omp_threads(threads)
+        one = dict(value=round(v_one, 4), cores=1,
+                   sample="%d^3 lattice volume: detect %.2f s + describe %.2f s, %d keypoints"
+                          % (n_one, d_one, e_one, k_one))
+    what = ("unmodified reference libsift3D (OpenMP)" if kind == "reference"
+            else "oracle restatement (OpenMP)")
+    out = dict(value=round(v_all, 4), unit="Mvoxel/s", cores=threads, kind=kind,
+               cpu_model=_cpu_model(),
+               sample="%d^3 lattice volume (1/%d of the workload's voxels), %s: detect %.2f s + "
+                      "describe %.2f s, %d keypoints" % (n_all, (512 // n_all) ** 3, what, d_all,
+                                                         e_all, k_all),
+               one_thread=one)
+    # context: the reference's own run of THIS workload (the 512^3 fixture, tests/golden/MANIFEST.json,
+    # generated in the 8-core build container with the default OpenMP thread count)
+    try:
+        man = json.load(open(os.path.join(ROOT, "tests", "golden", "MANIFEST.json")))["g5_512"]
+        out["reference_512_fixture"] = dict(
+            detect_s=man["t_detect"], describe_s=man["t_describe"],
+            value=round(512 ** 3 / 1e6 / (man["t_detect"] + man["t_describe"]), 4),
+            note="unmodified reference on the whole 512^3 workload when the fixture was made "
+                 "(build container, 8 cores, OMP default)")
+    except Exception:
+        pass
+    return out
 
 
 def main():
@@ -160,6 +212,10 @@ def main():
     ap.add_argument("--size", type=int, default=512, help="edge of the (per-GPU) volume")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-micro", action="store_true", help="skip the per-kernel microbench")
+    ap.add_argument("--strong", type=int, default=0, metavar="EDGE",
+                    help="strong scaling: ONE EDGE^3 volume (BASELINE configs[3]: 1024) cut into "
+                         "--gpus Z-slabs, instead of the default 512 planes per GPU")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
     ap.add_argument("--sharded", action="store_true",
                     help="N=1 only: run the Z-slab driver (sift3d_amd.sharded) instead of the C API, "
                          "to measure the driver's own overhead")
@@ -189,7 +245,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    n = a.size
+    n = a.strong if a.strong else a.size
+    nz_total = n if a.strong else n * world
     if world == 1 and not a.sharded:
         vol = torch.empty((n, n, n), device="cuda")
         hip.synth_lattice(vol, 0, 11)
@@ -203,18 +260,17 @@ def main():
             rc = det.extract_descriptors(kp, desc)
             assert rc == 0, "describe failed"
 
-        voxels_per_step = n ** 3
         stats = lambda: dict(candidates=det.num_candidates(), keypoints=len(kp),  # noqa: E731
                              stage_s={k: round(v, 6) for k, v in det.timings().items()})
         pyr_time = lambda: det.timings()["gauss_dev"]  # noqa: E731
     else:
         from sift3d_amd import sharded
-        job = sharded.ShardedSift3D(n, n, n * world, dist.group.WORLD if world > 1 else None)
+        job = sharded.ShardedSift3D(n, n, nz_total, dist.group.WORLD if world > 1 else None)
         job.synth(seed=11)
         step = job.step
-        voxels_per_step = n ** 3 * world
         stats = job.stats
         pyr_time = job.pyramid_seconds
+    voxels_per_step = n * n * nz_total
 
     for _ in range(a.warmup):
         step()
@@ -242,20 +298,26 @@ def main():
 
     ms_per_step = 1e3 * dt / a.steps
     value = voxels_per_step / 1e6 / (dt / a.steps)
+    if world == 1:
+        slabs = ""
+    elif a.strong:
+        slabs = " cut into %d Z-slabs" % world
+    else:
+        slabs = " as %d Z-slabs of %d planes" % (world, n)
     out = {
         "metric": "Mvoxel/s detect+describe (float32 volume resident in HBM)",
         "value": round(value, 2), "unit": "Mvoxel/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong" if a.strong else "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
         "config": {"workload": "%dx%dx%d float32 lattice-blob volume%s, detect+describe, default "
                                "parameters (sigma0 1.6, sigma_n 1.15, 3 levels/octave)"
-                               % (n, n, n * world, "" if world == 1 else
-                                  " as %d Z-slabs of %d planes" % (world, n)),
+                               % (n, n, nz_total, slabs),
                    "parallelism": "single GPU" if world == 1 else "z-slab x%d" % world},
     }
     out.update(stats())
     # pyramid roofline (whole Gaussian pyramid build, per GPU)
-    pbytes = pyramid_algorithmic_bytes(n, n, n)
+    pbytes = pyramid_algorithmic_bytes(n, n, nz_total // world)
     pt = float(np.median(pyr)) if pyr and pyr[0] else None
     pyramid = None
     if pt:
@@ -270,7 +332,31 @@ def main():
             traffic = json.load(open(tpath))
         except Exception:
             traffic = None
-    if world == 1 and not a.no_micro and not a.sharded:
+    # host-resident entry (sift3d_detect_keypoints on a sift3d_make_image volume in pageable host
+    # memory): the same K steps timed the same way, H2D copy included.  Reported beside `value`,
+    # never as `value`.
+    if world == 1 and not a.sharded and not a.no_host:
+        im = api.Image.from_array(vol.cpu().numpy())
+        kp2, desc2 = api.KeypointStore(), api.DescriptorStore()
+
+        def host_step():
+            assert det.detect_keypoints(im, kp2) == 0 and det.extract_descriptors(kp2, desc2) == 0
+
+        host_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            host_step()
+        torch.cuda.synchronize()
+        th = (time.perf_counter() - t0) / a.steps
+        assert len(kp2) == len(kp)
+        out["value_host_resident"] = {"value": round(voxels_per_step / 1e6 / th, 2), "unit": "Mvoxel/s",
+                                      "ms_per_step": round(1e3 * th, 3),
+                                      "note": "volume in pageable host memory, PCIe H2D inside the "
+                                              "timed region (sift3d_detect_keypoints on a "
+                                              "sift3d_image)"}
+        del im
+    if world == 1 and not a.no_micro and not a.sharded and not a.strong:
         kb = kernel_microbench(torch, hip, n)
         # dominant kernel = the pipeline kernel with the longest launch
         dom = max((k for k in kb if k["in_pipeline"]), key=lambda k: k["avg_ms"])
@@ -281,11 +367,34 @@ def main():
             sym = dom["kernel"].split(" (")[0]
             if sym in traffic:
                 tr = traffic[sym]["hbm_bytes"]
+        # `achieved` / `frac` price the ALGORITHMIC bytes (8 B per voxel and 1-D
+        # pass) against the HBM peak; `hbm_GBs` is what the kernel really moves (measured
+        # traffic / launch time): the fused y+z kernel keeps its intermediate on chip, so its
+        # HBM rate is about half its algorithmic rate.
         out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"],
                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": tr,
+                           "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                                             "WRITE_SIZE passes of this kernel, committed; not "
+                                             "measured in this run)",
+                           "hbm_GBs": round(tr / 1e9 / (dom["avg_ms"] * 1e-3), 1) if tr else None,
                            "algorithmic_bytes_per_launch": int(dom["algorithmic_GB"] * 1e9),
                            "avg_launch_ms": dom["avg_ms"], "pyramid": pyramid, "kernels": kb}
+        dpath = os.path.join(ROOT, "profiles", "describe_model.json")
+        if os.path.exists(dpath):
+            try:
+                dm = json.load(open(dpath))
+                dsec = out.get("stage_s", {}).get("describe")
+                if dsec and dm.get("valu_insts"):
+                    # issue-rate model of the descriptor kernel (VALU-issue / LDS-pipe bound, not HBM)
+                    simd_rate = 256 * 4 * 2.4e9 / dm.get("cycles_per_valu", 2.5)
+                    dm["achieved_valu_insts_per_s"] = round(dm["valu_insts"] / dsec, 1)
+                    dm["peak_valu_insts_per_s"] = round(simd_rate, 1)
+                    dm["frac"] = round(dm["valu_insts"] / dsec / simd_rate, 4)
+                    dm["seconds"] = dsec
+                    out["roofline"]["describe"] = dm
+            except Exception:
+                pass
     else:
         out["roofline"] = dict(pyramid or {}, kernel="Gaussian pyramid (all k_fir_* launches)",
                                traffic=None)
