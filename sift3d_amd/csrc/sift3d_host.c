@@ -1142,7 +1142,7 @@ static int blur_level(sift3d_detector *d, const float *src, float *dst, const in
     outs[2] = dst;
     /* tap spacing 1 on y and z (octave 0 of a unit-spaced volume): x pass, then the fused
      * y+z kernel -- the y-pass result never goes to HBM */
-    if ((float)(1.0 / lu[1]) == 1.0f && (float)(1.0 / lu[2]) == 1.0f && !getenv("SIFT3D_AMD_NO_FUSE")) {
+    if ((float)(1.0 / lu[1]) == 1.0f && (float)(1.0 / lu[2]) == 1.0f) {
         sift3d_hip_fir_args a;
         int rc;
         memset(&a, 0, sizeof(a));

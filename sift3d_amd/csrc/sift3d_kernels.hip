@@ -676,38 +676,83 @@ __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(1, 4)))
         return ld4(s + (size_t)i * nx);
     };
     // Tile rows of one plane held in registers: every thread stages row ty and, for the first
-    // 2*HW rows of threads, row ty + TY.  For HW <= 5 they are fetched ONE PLANE AHEAD (the
-    // `hint` of yfilt), so the global-load latency overlaps the FIR arithmetic of the current
-    // plane; wider filters have no registers to spare for that (occupancy would drop).
+    // 2*HW rows of threads, row ty + TY.  They are fetched PD PLANES AHEAD of their use: the rows
+    // of a plane are only ~1.5 16-byte loads per thread, and with one plane in flight a CU has
+    // ~24 KB outstanding -- a third of what the HBM latency needs at full rate.  Slot 0 of the
+    // queue is the plane the next call will ask for (exactly: `hint` follows the mirror /
+    // virtual planes at the global faces); the slots behind it are the following planes, which
+    // is what the sweep asks for everywhere but at those faces.  A wrong guess only costs a
+    // synchronous fetch (block-uniform branch).
     static_assert(2 * HW <= TY, "two tile rows per thread");
-    constexpr bool PF = HW <= 5;
-    float4 pr0 = make_float4(0.f, 0.f, 0.f, 0.f), pr1 = pr0;
-    int pre_pl = -(1 << 30);
+    // (depth: deeper queues measured no faster for HW <= 5; the 15- and 17-tap instances stage
+    // without prefetch -- their W-times unrolled sweep must stay inside the instruction cache)
+    constexpr int PD = HW <= 5 ? 1 : (HW == 6 ? 2 : 0);
+    constexpr int PQ = PD > 0 ? PD : 1;
+    constexpr int NONE = -(1 << 30);
+    float4 q0[PQ], q1[PQ];
+    int qpl[PQ];
+#pragma unroll
+    for (int i = 0; i < PQ; i++) {
+        q0[i] = q1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        qpl[i] = NONE;
+    }
     const bool second = ty + TY < ROWS;
-    auto fetch = [&](int pl) {
-        pr0 = ext_y(pl, y0 - HW + ty);
-        if (second)
-            pr1 = ext_y(pl, y0 - HW + ty + TY);
-        pre_pl = pl;
-    };
     // y-filtered value of this thread's column in local plane pl (block-wide call); `hint` is
     // the plane the next call will ask for (or < 0)
     auto yfilt = [&](int pl, int hint) -> float4 {
         pl = clampi(pl, 0, nl1);
-        if (PF) {
-            if (pre_pl != pl)                   // block-uniform
-                fetch(pl);
-            tile[buf][ty][qx] = pr0;
-            if (second)
-                tile[buf][ty + TY][qx] = pr1;
-        } else {
+        if (PD == 0) {
             // r -> (row, quad) with quad == qx because the block size is a multiple of TXQ
             for (int r = tid; r < ROWS * TXQ; r += TXQ * TY)
                 tile[buf][r / TXQ][qx] = ext_y(pl, y0 - HW + r / TXQ);
+            __syncthreads();
+            float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int dd = -HW; dd <= HW; dd++)
+                Vec<4>::mac(acc0, T.k[dd + HW], tile[buf][ty + HW - dd][qx]);
+            buf ^= 1;
+            return acc0;
         }
+        if (qpl[0] != pl) {                     // block-uniform: not prefetched
+            q0[0] = ext_y(pl, y0 - HW + ty);
+            if (second)
+                q1[0] = ext_y(pl, y0 - HW + ty + TY);
+            qpl[0] = pl;
+        }
+        tile[buf][ty][qx] = q0[0];
+        if (second)
+            tile[buf][ty + TY][qx] = q1[0];
         __syncthreads();
-        if (PF && hint >= 0)
-            fetch(clampi(hint, 0, nl1));
+        // advance the queue and top it up
+        const int nxt = hint >= 0 ? clampi(hint, 0, nl1) : NONE;
+#pragma unroll
+        for (int i = 0; i + 1 < PQ; i++) {
+            q0[i] = q0[i + 1];
+            q1[i] = q1[i + 1];
+            qpl[i] = qpl[i + 1];
+        }
+        qpl[PQ - 1] = NONE;
+        if (nxt != NONE && qpl[0] != nxt) {     // the sequence jumps (faces) or starts
+            q0[0] = ext_y(nxt, y0 - HW + ty);
+            if (second)
+                q1[0] = ext_y(nxt, y0 - HW + ty + TY);
+            qpl[0] = nxt;
+#pragma unroll
+            for (int i = 1; i < PQ; i++)
+                qpl[i] = NONE;
+        }
+#pragma unroll
+        for (int i = 1; i < PQ; i++) {
+            const int want = qpl[i - 1] == NONE || qpl[i - 1] >= nl1 ? NONE : qpl[i - 1] + 1;
+            if (qpl[i] != want) {
+                if (want != NONE) {
+                    q0[i] = ext_y(want, y0 - HW + ty);
+                    if (second)
+                        q1[i] = ext_y(want, y0 - HW + ty + TY);
+                }
+                qpl[i] = want;
+            }
+        }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int dd = -HW; dd <= HW; dd++)
@@ -744,7 +789,7 @@ __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(1, 4)))
                 np = 2;
             }
         }
-        const int nxt = PF ? first_plane(r + 1) : -1;
+        const int nxt = first_plane(r + 1);
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
 #pragma unroll 1
         for (int k = 0; k < np; k++) {
@@ -757,31 +802,35 @@ __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(1, 4)))
         return np == 2 ? Vec<4>::lerp(w0, a, w1, b) : a;
     };
 
-    // register window along z, oldest first: ring[i] holds extended plane q - HW + i
+    // Register window along z: the 2*HW+1 most recent extended planes.  The loop is unrolled W
+    // times so that every ring position is a compile-time register (as in k_fir_sweep_u1): at
+    // step j the window of output q holds plane q - HW + i in ring[(j + i) % W] -- nothing is
+    // ever shifted (a shifting window cost 4*2*HW register moves per plane, a third of the VALU
+    // instructions of this VALU-bound kernel).
     float4 ring[W];
 #pragma unroll
-    for (int i = 1; i < W; i++)
+    for (int i = 0; i < W; i++)
         ring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 1
-    for (int i = 0; i < 2 * HW; i++) {
+    // warm-up: planes p0 - HW .. p0 + HW - 1 into ring[0 .. 2*HW - 1] (static positions)
 #pragma unroll
-        for (int k = 0; k < W - 1; k++)
-            ring[k] = ring[k + 1];
-        ring[W - 1] = ext_z(p0 - HW + i);
-    }
+    for (int i = 0; i < 2 * HW; i++)
+        ring[i] = ext_z(p0 - HW + i);
     float *__restrict__ d = P.dst + (size_t)y * nx + x;
 #pragma unroll 1
-    for (int q = p0; q < p1; q++) {
+    for (int q0 = p0; q0 < p1; q0 += W) {
 #pragma unroll
-        for (int k = 0; k < W - 1; k++)
-            ring[k] = ring[k + 1];
-        ring[W - 1] = ext_z(q + HW);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < W; j++) {
+            const int q = q0 + j;
+            if (q < p1) {                              // block-uniform
+                ring[(j + 2 * HW) % W] = ext_z(q + HW);
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int dd = -HW; dd <= HW; dd++)
-            Vec<4>::mac(acc, T.k[dd + HW], ring[HW - dd]);   // E[q - d], d ascending
-        if (writer)
-            st4(d + (size_t)q * plane, acc);
+                for (int dd = -HW; dd <= HW; dd++)
+                    Vec<4>::mac(acc, T.k[dd + HW], ring[(j + HW - dd) % W]);   // E[q - d], d ascending
+                if (writer)
+                    st4(d + (size_t)q * plane, acc);
+            }
+        }
     }
 }
 
@@ -2605,12 +2654,13 @@ int sift3d_hip_fir_yz_u1(const float *d_src, float *d_dst, int nx, int ny, int n
     P.nx = nx; P.ny = ny; P.nz = nz;
     P.axis = 2; P.hw = hw; P.uf = 1.0f; P.uhw = hw;
     P.n_glob = n_glob; P.off = off; P.z_lo = z_lo; P.z_hi = z_hi;
-    // tile height: 32 rows measured best for every width (16 selectable for experiments)
-    static const int ty_env = getenv("SIFT3D_AMD_YZ_TY") ? atoi(getenv("SIFT3D_AMD_YZ_TY")) : 0;
-    const int ty = ty_env == 16 || ty_env == 32 ? ty_env : 32;
+    // tile height: 32 rows measured best for every width
+    const int ty = 32;
     {
         // z segmentation: >= 4096 waves in flight, segments of at least 32 planes
-        const long blocks_xy = (long)((nx / 4 + 15) / 16) * ((ny + ty - 1) / ty) * ty / 32;
+        long blocks_xy = (long)((nx / 4 + 15) / 16) * ((ny + ty - 1) / ty);
+        if (blocks_xy < 1)
+            blocks_xy = 1;
         const int n_out = z_hi - z_lo;
         long want = (512 + blocks_xy - 1) / blocks_xy;
         long cap = n_out / 32 > 1 ? n_out / 32 : 1;
@@ -2734,7 +2784,11 @@ int sift3d_hip_extrema_mode(const sift3d_hip_extrema_level *levels, int nlevels,
     uint32_t *blk = reinterpret_cast<uint32_t *>(masks + (size_t)nlevels * E.nwords);
     // default configuration (three keypoint levels sharing their DoG levels, whole quads): one z
     // sweep over the five DoG levels instead of three scattered-neighbour passes
-    static const bool no_sweep = getenv("SIFT3D_AMD_NO_EXSWEEP") != nullptr;
+#ifdef SIFT3D_AMD_DIAG
+    static const bool no_sweep = getenv("SIFT3D_AMD_NO_EXSWEEP") != nullptr;   // A/B of the sweep kernel
+#else
+    const bool no_sweep = false;
+#endif
     bool sweep = !E.cuboid && !no_sweep && nlevels == 3 && (nx & 3) == 0 && nz >= 3;
     if (sweep) {
         const float *ptrs[5] = { levels[0].prev, levels[0].cur, levels[1].cur, levels[2].cur, levels[2].next };
