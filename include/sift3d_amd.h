@@ -237,6 +237,25 @@ sift3d_hip_extrema_mode(const sift3d_hip_extrema_level *levels, int nlevels, int
                         double peak_thresh, int cuboid, sift3d_hip_cand *d_out, uint32_t cap,
                         uint32_t *d_count, void *d_work, size_t work_bytes, void *stream);
 
+/* build_dog + detect_extrema WITHOUT a stored DoG pyramid, default configuration (three keypoint
+ * levels per octave = six Gaussian levels, 8-neighbour test):
+ *   sift3d_hip_dogmax_stack    d_absmax[k] = max(d_absmax[k], max|d_g[k] - d_g[k+1]|), k < n_gauss-1
+ *                              (the dogmax scan, sift.c:821-826, on differences formed on the fly);
+ *   sift3d_hip_extrema_gauss6  detect_extrema for DoG levels 1..3 of the octave, the differences
+ *                              (im_subtract, imutil.c:719-739) again formed when loaded; records as
+ *                              sift3d_hip_extrema, tags tag0, tag0+1, tag0+2; d_absmax = the five
+ *                              maxima of the octave (global over slabs).
+ * Both return 1 (nothing done) when the configuration is not covered (nx % 4 != 0, unaligned
+ * levels, more than SIFT3D_HIP_MAX_DOG_STACK levels): the caller then stores the DoG levels
+ * (sift3d_hip_dog_stack) and calls sift3d_hip_extrema_mode. */
+SIFT3D_AMD_API int sift3d_hip_dogmax_stack(const float *const *d_g, int n_gauss, size_t n,
+                                           float *d_absmax, void *stream);
+SIFT3D_AMD_API int
+sift3d_hip_extrema_gauss6(const float *const *d_g, const float *d_absmax, int nx, int ny, int nz,
+                          int z_lo, int z_hi, int tag0, double peak_thresh, sift3d_hip_cand *d_out,
+                          uint32_t cap, uint32_t *d_count, void *d_work, size_t work_bytes,
+                          void *stream);
+
 /* Geometry of one Gaussian level, as the window kernels see it (a table of these
  * lives in device memory, indexed by the `tag`/`level` of a record). */
 typedef struct {

@@ -113,7 +113,8 @@ struct _sift3d_detector {
     void *ev_chunk[8];
     float *d_im, *d_tmp_a, *d_tmp_b, *d_in;
     size_t in_cap;
-    float **d_g, **d_d;    /* [num_octaves*ngl], [num_octaves*ndl] */
+    float **d_g, **d_d;    /* [num_octaves*ngl], [num_octaves*ndl] (DoG: only where stored) */
+    unsigned char dog_free[64]; /* per octave: the last detect formed its DoG levels on the fly */
     float *d_scalars;      /* [0] input max, [1] count (as u32), [8 + o*ndl + s] dogmax */
     sift3d_hip_level *h_levels, *d_levels;
     sift3d_hip_cand *d_cand, *h_cand;
@@ -938,9 +939,7 @@ static int resize_detector(sift3d_detector *d)
         for (s = 0; s < ngl; s++)
             if (!(d->d_g[o * ngl + s] = (float *)sift3d_hip_malloc(n * sizeof(float))))
                 return SIFT3D_FAILURE;
-        for (s = 0; s < ndl; s++)
-            if (!(d->d_d[o * ndl + s] = (float *)sift3d_hip_malloc(n * sizeof(float))))
-                return SIFT3D_FAILURE;
+        /* (DoG levels are allocated only where an octave needs them stored: ensure_dog_octave) */
         work = w > work ? w : work;
         for (s = 0; s < 3; s++)
             dims[s] /= 2;                            /* imutil.c:1545-1547 */
@@ -1129,6 +1128,19 @@ static int ensure_cand_capacity(sift3d_detector *d, uint32_t cap)
     return SIFT3D_SUCCESS;
 }
 
+/* DoG levels of one octave in memory -- only for configurations the DoG-free extrema sweep
+ * does not cover (sift3d_hip_extrema_gauss6) */
+static int ensure_dog_octave(sift3d_detector *d, int o)
+{
+    const size_t n = (size_t)d->odims[o][0] * d->odims[o][1] * d->odims[o][2];
+    int s;
+    for (s = 0; s < d->ndl; s++)
+        if (!d->d_d[o * d->ndl + s] &&
+            !(d->d_d[o * d->ndl + s] = (float *)sift3d_hip_malloc(n * sizeof(float))))
+            return SIFT3D_FAILURE;
+    return SIFT3D_SUCCESS;
+}
+
 /* apply_Sep_FIR_filter (imutil.c:1127-1206) on the device: x, y, z passes, the two
  * intermediates in scratch volumes, no permute copies */
 static int blur_level(sift3d_detector *d, const float *src, float *dst, const int *dims,
@@ -1260,13 +1272,26 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     }
     sift3d_hip_event_record(d->ev[2], d->stream);
 
-    /* build_dog (sift.c:713-732) fused with the dogmax scan (sift.c:821-826) */
+    /* build_dog (sift.c:713-732) + the dogmax scan (sift.c:821-826).  Default configuration: only
+     * the maxima are computed here; the extrema sweep forms the differences itself and no DoG
+     * level is stored.  Otherwise (cuboid neighbourhood, another level count, rows that are not
+     * whole quads) the octave's DoG levels are stored as the reference does. */
     for (o = 0; o < d->num_octaves; o++) {
         const size_t n = (size_t)d->odims[o][0] * d->odims[o][1] * d->odims[o][2];
+        int rc = 1;
+        d->dog_free[o] = 0;
+        if (!d->cuboid_extrema && d->ngl == 6 && (d->odims[o][0] & 3) == 0 && d->odims[o][2] >= 3)
+            rc = sift3d_hip_dogmax_stack((const float *const *)(d->d_g + o * d->ngl), d->ngl, n,
+                                         d->d_scalars + 8 + o * d->ndl, d->stream);
+        if (rc == SIFT3D_SUCCESS) {
+            d->dog_free[o] = 1;
+            continue;
+        }
+        if (rc != 1 || ensure_dog_octave(d, o))
+            return SIFT3D_FAILURE;
         /* one pass over the octave's Gaussian levels when the stack kernel covers it */
-        const int rc = sift3d_hip_dog_stack((const float *const *)(d->d_g + o * d->ngl),
-                                            d->d_d + o * d->ndl, d->ngl, n,
-                                            d->d_scalars + 8 + o * d->ndl, d->stream);
+        rc = sift3d_hip_dog_stack((const float *const *)(d->d_g + o * d->ngl), d->d_d + o * d->ndl,
+                                  d->ngl, n, d->d_scalars + 8 + o * d->ndl, d->stream);
         if (rc == SIFT3D_SUCCESS)
             continue;
         if (rc != 1)
@@ -1295,6 +1320,16 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
             if (nl > 8) {
                 ERR("sift3d_amd: at most 8 keypoint levels per octave are supported \n");
                 return SIFT3D_FAILURE;
+            }
+            if (d->dog_free[o]) {
+                const int rc = sift3d_hip_extrema_gauss6(
+                    (const float *const *)(d->d_g + o * d->ngl), d->d_scalars + 8 + o * d->ndl,
+                    d->odims[o][0], d->odims[o][1], d->odims[o][2], 1, d->odims[o][2] - 1,
+                    o * d->ngl + 1, d->peak_thresh, d->d_cand, d->cand_cap,
+                    (uint32_t *)(d->d_scalars + 1), d->d_work, d->work_bytes, d->stream);
+                if (rc == SIFT3D_SUCCESS)
+                    continue;
+                return SIFT3D_FAILURE;       /* (coverage was established by the dogmax call) */
             }
             for (s = 0; s < nl; s++) {
                 lv[s].prev = d->d_d[o * d->ndl + s];
@@ -1550,7 +1585,19 @@ int sift3d_amd_copy_level(const sift3d_detector *d, int which, int o, int s, flo
         const int nl = which == 0 ? d->ngl : d->ndl;
         if (o < 0 || o >= d->num_octaves || s < -1 || s > nl - 2)
             return SIFT3D_FAILURE;
-        src = which == 0 ? d->d_g[o * d->ngl + s + 1] : d->d_d[o * d->ndl + s + 1];
+        if (which == 0) {
+            src = d->d_g[o * d->ngl + s + 1];
+        } else if (d->d_d[o * d->ndl + s + 1] && !d->dog_free[o]) {
+            src = d->d_d[o * d->ndl + s + 1];
+        } else {
+            /* the DoG level was never stored: form it now (im_subtract, imutil.c:719-739) in
+             * scratch */
+            const size_t nn = (size_t)d->odims[o][0] * d->odims[o][1] * d->odims[o][2];
+            if (sift3d_hip_subtract_absmax(d->d_g[o * d->ngl + s + 1], d->d_g[o * d->ngl + s + 2],
+                                           d->d_tmp_a, nn, NULL, d->stream))
+                return SIFT3D_FAILURE;
+            src = d->d_tmp_a;
+        }
     }
     if (dims)
         memcpy(dims, d->odims[o], sizeof(int) * 3);

@@ -224,6 +224,29 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return v;
 }
 
+// max over the workgroup (256 threads) of non-negative floats, then ONE atomic per workgroup.
+// Same-address atomics serialise at the memory side (~20 ns each): one per wave cost the DoG
+// kernels 1.5 ms at 512^3.  NM maxima at once; non-negative floats order like their bit patterns.
+template <int NM>
+__device__ __forceinline__ void block_max_atomic(const float *m, unsigned *__restrict__ out)
+{
+    __shared__ float red[NM][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < NM; k++) {
+        const float w = wave_max(m[k]);
+        if (lane == 0)
+            red[k][wave] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < NM) {
+        const float w = fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]),
+                              fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]));
+        if (w > 0.0f)
+            atomicMax(out + threadIdx.x, __float_as_uint(w));
+    }
+}
+
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
@@ -239,16 +262,24 @@ __global__ __launch_bounds__(256) void k_absmax(const float *__restrict__ src, s
     const size_t nthr = (size_t)gridDim.x * blockDim.x;
     const size_t n4 = n >> 2;
     float m = 0.0f;
-    for (size_t i = tid; i < n4; i += nthr) {
+    // four independent 16-byte loads in flight per thread and iteration
+    size_t i = tid;
+    for (; i + 3 * nthr < n4; i += 4 * nthr) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            v[k] = ld4(src + 4 * (i + k * nthr));
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[k].x), fabsf(v[k].y)), fmaxf(fabsf(v[k].z), fabsf(v[k].w))));
+    }
+    for (; i < n4; i += nthr) {
         const float4 v = ld4(src + 4 * i);
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
-    for (size_t i = 4 * n4 + tid; i < n; i += nthr)
-        m = fmaxf(m, fabsf(src[i]));
-    m = wave_max(m);
-    // non-negative floats order like their bit patterns
-    if ((threadIdx.x & 63) == 0 && m > 0.0f)
-        atomicMax(out, __float_as_uint(m));
+    for (size_t j = 4 * n4 + tid; j < n; j += nthr)
+        m = fmaxf(m, fabsf(src[j]));
+    block_max_atomic<1>(&m, out);
 }
 
 __global__ __launch_bounds__(256) void k_scale(const float *__restrict__ src,
@@ -1122,11 +1153,8 @@ __global__ __launch_bounds__(256) void k_sub_absmax(const float *__restrict__ a,
         dst[j] = r;
         m = fmaxf(m, fabsf(r));
     }
-    if (out) {
-        m = wave_max(m);
-        if ((threadIdx.x & 63) == 0 && m > 0.0f)
-            atomicMax(out, __float_as_uint(m));
-    }
+    if (out)                                   // kernel argument: uniform
+        block_max_atomic<1>(&m, out);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1176,12 +1204,45 @@ __global__ __launch_bounds__(256) void k_dog_stack(DogStack S, size_t n)
             prev = cur;
         }
     }
+    block_max_atomic<NL - 1>(m, S.out);
+}
+
+// The same maxima without the DoG levels themselves: the extrema sweep below forms the
+// differences on the fly from the Gaussian levels, so the DoG pyramid is never stored
+// (24 B/voxel read here instead of 24 B read + 20 B written, and 5/11 of the pyramid memory).
+template <int NL>
+__global__ __launch_bounds__(256) void k_dogmax_stack(DogStack S, size_t n)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthr = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = n >> 2;
+    float m[NL - 1];
 #pragma unroll
-    for (int k = 0; k < NL - 1; k++) {
-        const float w = wave_max(m[k]);
-        if ((threadIdx.x & 63) == 0 && w > 0.0f)
-            atomicMax(S.out + k, __float_as_uint(w));
+    for (int k = 0; k < NL - 1; k++)
+        m[k] = 0.0f;
+    for (size_t i = tid; i < n4; i += nthr) {
+        float4 v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++)
+            v[k] = ld4(S.g[k] + 4 * i);
+#pragma unroll
+        for (int k = 0; k < NL - 1; k++) {
+            float4 r;
+            r.x = v[k].x - v[k + 1].x; r.y = v[k].y - v[k + 1].y;
+            r.z = v[k].z - v[k + 1].z; r.w = v[k].w - v[k + 1].w;
+            m[k] = fmaxf(m[k], fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
+        }
     }
+    for (size_t j = 4 * n4 + tid; j < n; j += nthr) {
+        float prev = S.g[0][j];
+#pragma unroll
+        for (int k = 0; k < NL - 1; k++) {
+            const float cur = S.g[k + 1][j];
+            m[k] = fmaxf(m[k], fabsf(prev - cur));
+            prev = cur;
+        }
+    }
+    block_max_atomic<NL - 1>(m, S.out);
 }
 
 __global__ __launch_bounds__(256) void k_downsample2(const float *__restrict__ src, int nx, int ny,
@@ -1326,7 +1387,8 @@ __global__ __launch_bounds__(256) void k_extrema_mask(ExLevels LV, ExGeom E,
 // 64-voxel mask words as k_extrema_mask, assembled with a DPP OR-reduction over the 16 lanes of
 // a row, so the scan and emit kernels (and with them the reference's scan order) are unchanged.
 struct ExSweep {
-    const float *d[5];        // DoG levels s-1 .. s+3 of the three keypoint levels
+    const float *d[6];        // DoG levels s-1 .. s+3 of the three keypoint levels -- or, for the
+                              // FROM_G instance, the SIX Gaussian levels they are differences of
     const float *absmax[3];
     double peak_thresh;
     int nx, ny, nz;           // local dims
@@ -1341,8 +1403,20 @@ template <int CTRL> __device__ __forceinline__ int dpp_i(int v)
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);   // out-of-row lanes read 0
 }
 
+// FROM_G: level k of the sweep is Gaussian level k minus Gaussian level k + 1 (im_subtract,
+// imutil.c:719-739), formed when loaded -- the same float subtraction build_dog stores.
+template <bool FROM_G>
 __global__ __launch_bounds__(256) void k_extrema_sweep3(ExSweep S)
 {
+    auto ldd4 = [&](int k, size_t o) -> float4 {
+        if (!FROM_G)
+            return ld4(S.d[k] + o);
+        const float4 a = ld4(S.d[k] + o), b = ld4(S.d[k + 1] + o);
+        return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    };
+    auto ldd1 = [&](int k, size_t o) -> float {
+        return FROM_G ? S.d[k][o] - S.d[k + 1][o] : S.d[k][o];
+    };
     constexpr int TY = 16;
     const int qx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int x = (blockIdx.x * 16 + qx) * 4, y = blockIdx.y * TY + ty;
@@ -1367,8 +1441,8 @@ __global__ __launch_bounds__(256) void k_extrema_sweep3(ExSweep S)
     float4 m[3], c[3], p[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        m[i] = ld4(S.d[i + 1] + (size_t)(p0 - 1) * zs + oc);
-        c[i] = ld4(S.d[i + 1] + (size_t)p0 * zs + oc);
+        m[i] = ldd4(i + 1, (size_t)(p0 - 1) * zs + oc);
+        c[i] = ldd4(i + 1, (size_t)p0 * zs + oc);
     }
 #pragma unroll 1
     for (int z = p0; z < p1; z++) {
@@ -1377,20 +1451,19 @@ __global__ __launch_bounds__(256) void k_extrema_sweep3(ExSweep S)
         float lf[3], rt[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            const float *lv = S.d[i + 1];
-            p[i] = ld4(lv + zo + zs + oc);
-            up[i] = ld4(lv + zo + ou);
-            dn[i] = ld4(lv + zo + od);
+            p[i] = ldd4(i + 1, zo + zs + oc);
+            up[i] = ldd4(i + 1, zo + ou);
+            dn[i] = ldd4(i + 1, zo + od);
             // x neighbours of the quad's ends: adjacent lanes of the 16-lane row, or memory at
             // the ends of the 64-voxel tile
             lf[i] = __int_as_float(dpp_i<0x111>(__float_as_int(c[i].w)));   // row_shr:1
             rt[i] = __int_as_float(dpp_i<0x101>(__float_as_int(c[i].x)));   // row_shl:1
             if (qx == 0 && col && x > 0)
-                lf[i] = lv[zo + oc - 1];
+                lf[i] = ldd1(i + 1, zo + oc - 1);
             if (qx == 15 && col && x + 4 < nx)
-                rt[i] = lv[zo + oc + 4];
+                rt[i] = ldd1(i + 1, zo + oc + 4);
         }
-        const float4 d0c = ld4(S.d[0] + zo + oc), d4c = ld4(S.d[4] + zo + oc);
+        const float4 d0c = ldd4(0, zo + oc), d4c = ldd4(4, zo + oc);
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const float4 pv = i == 0 ? d0c : c[i - 1], nv = i == 2 ? d4c : c[i + 1];
@@ -1484,6 +1557,9 @@ __global__ __launch_bounds__(1024) void k_extrema_scan(uint32_t *__restrict__ bl
         *d_count = carry;
 }
 
+// FROM_G: `cur` and `next` of a level hold the two Gaussian levels whose difference is the DoG
+// level (the DoG pyramid is not stored)
+template <bool FROM_G>
 __global__ __launch_bounds__(256) void k_extrema_emit(ExLevels LV, ExGeom E,
                                                       const unsigned long long *__restrict__ masks,
                                                       const uint32_t *__restrict__ blk_off,
@@ -1537,7 +1613,7 @@ __global__ __launch_bounds__(256) void k_extrema_emit(ExLevels LV, ExGeom E,
         sift3d_hip_cand c;
         c.idx = (uint32_t)p;
         c.tag = L.tag;
-        c.val = fabsf(L.cur[p]);                                     // sift.c:864
+        c.val = fabsf(FROM_G ? L.cur[p] - L.next[p] : L.cur[p]);     // sift.c:864
         out[pos] = c;
     }
 }
@@ -2329,6 +2405,14 @@ __global__ void k_test_eigen3(const double *A, double *Q, double *L, size_t n)
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+static int grid_for(size_t n, int per_thread);
+// streaming reductions: few, long-running workgroups (one atomic each at the end)
+static int grid_reduce(size_t n)
+{
+    const int b = grid_for(n, 4);
+    return b < 256 * 4 ? b : 256 * 4;
+}
+
 static int grid_for(size_t n, int per_thread)
 {
     size_t b = (n / per_thread + 255) / 256;
@@ -2477,7 +2561,7 @@ static void launch_fir_yz(const FirParams &P, const FirTaps &T, const EdgeTab &E
 template <int NL>
 static void launch_dog_stack(const DogStack &S, size_t n, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_dog_stack<NL>), dim3(grid_for(n, 8)), dim3(256), 0, st, S, n);
+    hipLaunchKernelGGL((k_dog_stack<NL>), dim3(grid_reduce(n)), dim3(256), 0, st, S, n);
 }
 
 static bool is_dyadic(float uf, int *shift)
@@ -2496,7 +2580,7 @@ int sift3d_hip_absmax(const float *d_src, size_t n, float *d_max, void *stream)
 {
     if (!n)
         return SIFT3D_SUCCESS;
-    hipLaunchKernelGGL(k_absmax, dim3(grid_for(n, 16)), dim3(256), 0, (hipStream_t)stream, d_src, n,
+    hipLaunchKernelGGL(k_absmax, dim3(grid_reduce(n)), dim3(256), 0, (hipStream_t)stream, d_src, n,
                        reinterpret_cast<unsigned *>(d_max));
     LAUNCH_CHECK();
     return SIFT3D_SUCCESS;
@@ -2689,7 +2773,7 @@ int sift3d_hip_subtract_absmax(const float *d_a, const float *d_b, float *d_dst,
 {
     if (!n)
         return SIFT3D_SUCCESS;
-    hipLaunchKernelGGL(k_sub_absmax, dim3(grid_for(n, 16)), dim3(256), 0, (hipStream_t)stream, d_a,
+    hipLaunchKernelGGL(k_sub_absmax, dim3(grid_reduce(n)), dim3(256), 0, (hipStream_t)stream, d_a,
                        d_b, d_dst, n, reinterpret_cast<unsigned *>(d_absmax));
     LAUNCH_CHECK();
     return SIFT3D_SUCCESS;
@@ -2820,7 +2904,7 @@ int sift3d_hip_extrema_mode(const sift3d_hip_extrema_level *levels, int nlevels,
                 nseg = nseg < cap_seg ? nseg : cap_seg;
                 S.ts = (int)((n_out + nseg - 1) / nseg);
                 dim3 grid((nx + 63) / 64, (ny + 15) / 16, (n_out + S.ts - 1) / S.ts);
-                hipLaunchKernelGGL(k_extrema_sweep3, grid, dim3(256), 0, st, S);
+                hipLaunchKernelGGL(k_extrema_sweep3<false>, grid, dim3(256), 0, st, S);
             }
             hipLaunchKernelGGL(k_extrema_count, dim3(E.nblk, 3), dim3(256), 0, st, masks, E.nwords,
                                E.nblk, blk);
@@ -2836,8 +2920,94 @@ int sift3d_hip_extrema_mode(const sift3d_hip_extrema_level *levels, int nlevels,
                            blk);
     hipLaunchKernelGGL(k_extrema_scan, dim3(1), dim3(1024), 0, st, blk, E.nblk * (uint32_t)nlevels,
                        d_count);
-    hipLaunchKernelGGL(k_extrema_emit, dim3(E.nblk, nlevels), dim3(256), 0, st, LV, E, masks, blk,
+    hipLaunchKernelGGL(k_extrema_emit<false>, dim3(E.nblk, nlevels), dim3(256), 0, st, LV, E, masks, blk,
                        d_out, cap);
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_dogmax_stack(const float *const *d_g, int n_gauss, size_t n, float *d_absmax, void *stream)
+{
+    if (n_gauss < 2 || n_gauss > SIFT3D_HIP_MAX_DOG_STACK)
+        return 1; // not covered
+    if (!n)
+        return SIFT3D_SUCCESS;
+    DogStack S;
+    memset(&S, 0, sizeof(S));
+    for (int k = 0; k < n_gauss; k++) {
+        S.g[k] = d_g[k];
+        if ((uintptr_t)d_g[k] & 15)
+            return 1;
+    }
+    S.out = reinterpret_cast<unsigned *>(d_absmax);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(grid_reduce(n)), block(256);
+    switch (n_gauss) {
+    case 2: hipLaunchKernelGGL((k_dogmax_stack<2>), grid, block, 0, st, S, n); break;
+    case 3: hipLaunchKernelGGL((k_dogmax_stack<3>), grid, block, 0, st, S, n); break;
+    case 4: hipLaunchKernelGGL((k_dogmax_stack<4>), grid, block, 0, st, S, n); break;
+    case 5: hipLaunchKernelGGL((k_dogmax_stack<5>), grid, block, 0, st, S, n); break;
+    case 6: hipLaunchKernelGGL((k_dogmax_stack<6>), grid, block, 0, st, S, n); break;
+    case 7: hipLaunchKernelGGL((k_dogmax_stack<7>), grid, block, 0, st, S, n); break;
+    default: hipLaunchKernelGGL((k_dogmax_stack<8>), grid, block, 0, st, S, n); break;
+    }
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_extrema_gauss6(const float *const *d_g, const float *d_absmax, int nx, int ny, int nz,
+                              int z_lo, int z_hi, int tag0, double peak_thresh, sift3d_hip_cand *d_out,
+                              uint32_t cap, uint32_t *d_count, void *d_work, size_t work_bytes,
+                              void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if ((size_t)nx * ny * nz >= (1ull << 32) || work_bytes < sift3d_hip_extrema_work_bytes(nx, ny, nz, 3)) {
+        snprintf(g_err, sizeof(g_err), "sift3d_hip_extrema_gauss6: invalid arguments");
+        fprintf(stderr, "sift3d_amd: %s\n", g_err);
+        return SIFT3D_FAILURE;
+    }
+    // covered: whole quads, aligned levels, at least one interior plane
+    if ((nx & 3) || nz < 3 || z_lo < 1 || z_hi > nz - 1)
+        return 1;
+    for (int i = 0; i < 6; i++)
+        if ((uintptr_t)d_g[i] & 15)
+            return 1;
+    const ExGeom E = ex_geom(nx, ny, nz, peak_thresh, 0);
+    unsigned long long *masks = reinterpret_cast<unsigned long long *>(d_work);
+    uint32_t *blk = reinterpret_cast<uint32_t *>(masks + (size_t)3 * E.nwords);
+    ExSweep S;
+    memset(&S, 0, sizeof(S));
+    for (int i = 0; i < 6; i++)
+        S.d[i] = d_g[i];
+    for (int i = 0; i < 3; i++)
+        S.absmax[i] = d_absmax + 1 + i;       // DoG levels 1..3 are the keypoint levels
+    S.peak_thresh = peak_thresh;
+    S.nx = nx; S.ny = ny; S.nz = nz;
+    S.z_lo = z_lo; S.z_hi = z_hi;
+    S.wpr = E.wpr; S.nwords = E.nwords;
+    S.masks32 = reinterpret_cast<uint32_t *>(masks);
+    const int n_out = z_hi - z_lo;
+    HIPCHK(hipMemsetAsync(masks, 0, (size_t)3 * E.nwords * 8, st));
+    if (n_out > 0) {
+        const long bxy = (long)((nx + 63) / 64) * ((ny + 15) / 16);
+        long nseg = (2048 + bxy - 1) / bxy;
+        const long cap_seg = n_out / 16 > 1 ? n_out / 16 : 1;
+        nseg = nseg < cap_seg ? nseg : cap_seg;
+        S.ts = (int)((n_out + nseg - 1) / nseg);
+        dim3 grid((nx + 63) / 64, (ny + 15) / 16, (n_out + S.ts - 1) / S.ts);
+        hipLaunchKernelGGL(k_extrema_sweep3<true>, grid, dim3(256), 0, st, S);
+    }
+    hipLaunchKernelGGL(k_extrema_count, dim3(E.nblk, 3), dim3(256), 0, st, masks, E.nwords, E.nblk, blk);
+    hipLaunchKernelGGL(k_extrema_scan, dim3(1), dim3(1024), 0, st, blk, E.nblk * 3u, d_count);
+    ExLevels LV;
+    memset(&LV, 0, sizeof(LV));
+    for (int i = 0; i < 3; i++) {
+        LV.lv[i].cur = d_g[i + 1];            // DoG level i + 1 = G[i + 1] - G[i + 2]
+        LV.lv[i].next = d_g[i + 2];
+        LV.lv[i].tag = tag0 + i;
+    }
+    hipLaunchKernelGGL(k_extrema_emit<true>, dim3(E.nblk, 3), dim3(256), 0, st, LV, E, masks, blk, d_out,
+                       cap);
     LAUNCH_CHECK();
     return SIFT3D_SUCCESS;
 }
