@@ -89,6 +89,12 @@ sift3d_amd_keypoint_store_set(sift3d_keypoint_store *, int n, const int *os /*2n
                               const float *R /*9n*/);
 SIFT3D_AMD_API int
 sift3d_amd_descriptor_store_size(const sift3d_descriptor_store *);
+/* Fill a descriptor store from host arrays (n records of {x, y, z, sd} and 768 floats; the image
+ * dimensions the reference keeps in the store): lets the writers and converters be checked
+ * against reference-written files without a device. */
+SIFT3D_AMD_API int
+sift3d_amd_descriptor_store_set(sift3d_descriptor_store *, int n, const double *xyz_sd /*4n*/,
+                                const float *hist /*768n*/, int nx, int ny, int nz);
 
 /* init_Gauss_filter (imutil.c:1267-1319) on the host: normalised taps for `sigma`.
  * Returns the width (taps are written when width <= max_taps) or -1. */

@@ -227,6 +227,39 @@ def end_to_end_digest(name, vol, stride=97, input_spec=None):
                        t_describe=round(t_desc, 2))}
 
 
+def g4_csv():
+    """Files written by the reference's own sift3d_keypoint_store_save /
+    sift3d_descriptor_store_save (sift.c:1741-1830 via write_Mat_rm, imutil.c:405-479), plain and
+    gzip, for the g3_64 volume -- as DATA: the whole keypoint file (a few KB of numbers), sha1 +
+    size + first / last rows of the descriptor file, and the records they were written from."""
+    import gzip
+    import hashlib
+    import tempfile
+    vol = so.synth_survey(64)
+    p = refprobe.Probe()
+    assert p.detect(vol) == 0 and p.describe() == 0
+    k = p.keypoints()
+    h, x = p.descriptors()
+    d = {"kp_os": k["os"], "kp_xyzsd": k["xyzsd"], "kp_strength": k["strength"], "kp_R": k["R"],
+         "desc_hist": h, "desc_xyzsd": x, "dims": np.array(vol.shape[::-1], np.int32)}
+    with tempfile.TemporaryDirectory() as t:
+        kp, dp = os.path.join(t, "kp.csv"), os.path.join(t, "desc.csv")
+        assert p.save(kp, dp) == 0
+        assert p.save(kp + ".gz", dp + ".gz") == 0
+        ktxt, dtxt = open(kp, "rb").read(), open(dp, "rb").read()
+        assert gzip.open(kp + ".gz", "rb").read() == ktxt and gzip.open(dp + ".gz", "rb").read() == dtxt
+    rows = dtxt.split(b"\n")
+    d["kp_csv"] = np.frombuffer(ktxt, np.uint8)
+    d["desc_csv_sha1"] = np.array(hashlib.sha1(dtxt).hexdigest())
+    d["desc_csv_bytes"] = np.array(len(dtxt))
+    d["desc_csv_first_row"] = np.frombuffer(rows[0], np.uint8)
+    d["desc_csv_last_row"] = np.frombuffer(rows[-2] if rows[-1] == b"" else rows[-1], np.uint8)
+    d["desc_csv_ends_with_newline"] = np.array(dtxt.endswith(b"\n"))
+    p.close()
+    np.savez_compressed(os.path.join(OUT, "g4_csv.npz"), **d)
+    return {"g4_csv": dict(kp=int(len(k["strength"])), kp_csv_bytes=len(ktxt), desc_csv_bytes=len(dtxt))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also 128^3 and 256^3 (minutes)")
@@ -259,6 +292,7 @@ def main():
                                       input_spec=dict(gen="lattice", n=[50, 44, 40], seed=9)),
         "g3_lat": lambda: end_to_end("g3_lattice48", so.synth_lattice(48, seed=7),
                                      input_spec=dict(gen="lattice", n=48, seed=7)),
+        "g4_csv": g4_csv,
     }
     if a.big:
         jobs["g5_128"] = lambda: end_to_end(

@@ -80,6 +80,7 @@ def lib():
                                                     C.POINTER(C.c_float), _f32p]),
         "sift3d_amd_keypoint_store_set": (C.c_int, [vp, C.c_int, _i32p, _f64p, _f32p, _f32p]),
         "sift3d_amd_descriptor_store_size": (C.c_int, [vp]),
+        "sift3d_amd_descriptor_store_set": (C.c_int, [vp, C.c_int, _f64p, _f32p, C.c_int, C.c_int, C.c_int]),
         "sift3d_amd_device_available": (C.c_int, []),
         "sift3d_amd_version": (C.c_char_p, []),
         "sift3d_amd_synth_survey": (None, [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]),
@@ -273,6 +274,18 @@ class DescriptorStore:
 
     def save(self, path):
         return lib().sift3d_descriptor_store_save(path.encode(), self.h)
+
+    def set(self, xyz_sd, hist, dims=(0, 0, 0)):
+        """Fill the store from host arrays (tests of the writers without a device)."""
+        xyz_sd = np.ascontiguousarray(xyz_sd, np.float64).reshape(-1, 4)
+        hist = np.ascontiguousarray(hist, np.float32).reshape(-1, 768)
+        assert len(xyz_sd) == len(hist)
+        if len(hist) == 0:
+            xyz_sd, hist = np.zeros((1, 4)), np.zeros((1, 768), np.float32)
+            return lib().sift3d_amd_descriptor_store_set(self.h, 0, xyz_sd.reshape(-1), hist.reshape(-1),
+                                                         *[int(v) for v in dims])
+        return lib().sift3d_amd_descriptor_store_set(self.h, len(hist), xyz_sd.reshape(-1),
+                                                     hist.reshape(-1), *[int(v) for v in dims])
 
 
 class Detector:

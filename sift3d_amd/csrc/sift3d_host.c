@@ -655,6 +655,29 @@ int sift3d_descriptor_store_save(const char *path, const sift3d_descriptor_store
 int sift3d_amd_keypoint_store_size(const sift3d_keypoint_store *kp) { return (int)kp->num; }
 int sift3d_amd_descriptor_store_size(const sift3d_descriptor_store *d) { return (int)d->num; }
 
+/* Fill a descriptor store from host arrays (tests of the writers / converters without a
+ * device): n records of {x, y, z, sd} (doubles) and 768 floats. */
+int sift3d_amd_descriptor_store_set(sift3d_descriptor_store *d, int n, const double *xyz_sd,
+                                    const float *hist, int nx, int ny, int nz)
+{
+    if (!d || n < 0 || (n && (!xyz_sd || !hist)))
+        return SIFT3D_FAILURE;
+    desc_store_release(d);
+    if (n) {
+        d->hist = (float *)malloc(sizeof(float) * DESC_NUMEL * (size_t)n);
+        d->xyzsd = (double *)malloc(sizeof(double) * 4 * (size_t)n);
+        if (!d->hist || !d->xyzsd) {
+            desc_store_release(d);
+            return SIFT3D_FAILURE;
+        }
+        memcpy(d->hist, hist, sizeof(float) * DESC_NUMEL * (size_t)n);
+        memcpy(d->xyzsd, xyz_sd, sizeof(double) * 4 * (size_t)n);
+    }
+    d->cap = d->num = (size_t)n;
+    d->nx = nx; d->ny = ny; d->nz = nz;
+    return SIFT3D_SUCCESS;
+}
+
 int sift3d_amd_keypoint_store_get(const sift3d_keypoint_store *kp, int i, int *o, int *s,
                                   double *xyz_sd, float *strength, float *R)
 {

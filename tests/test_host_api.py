@@ -148,6 +148,48 @@ def test_csv_writers(api, tmp_path):
         d.to_mat_rm()
 
 
+def test_csv_writers_against_reference_files(api, tmp_path):
+    """sift3d_keypoint_store_save / sift3d_descriptor_store_save against files the UNMODIFIED
+    reference wrote for the same records (tests/golden/g4_csv.npz, made by oracle/make_golden.py
+    g4_csv: sift.c:1741-1830, write_Mat_rm imutil.c:405-479) -- byte for byte, plain and gzip."""
+    import hashlib
+    from sift3d_amd.api import KP_DTYPE
+    from tests import util
+    g = util.load("g4_csv")
+    n = len(g["kp_strength"])
+    recs = np.zeros(n, KP_DTYPE)
+    recs["o"], recs["s"] = g["kp_os"][:, 0], g["kp_os"][:, 1]
+    for i, f in enumerate(("xd", "yd", "zd", "sd")):
+        recs[f] = g["kp_xyzsd"][:, i]
+    recs["strength"] = g["kp_strength"]
+    recs["R"] = g["kp_R"].reshape(n, 3, 3)
+    kp = api.KeypointStore()
+    assert kp.set_records(recs) == 0
+    want = bytes(g["kp_csv"])
+    p = str(tmp_path / "kp.csv")
+    assert kp.save(p) == 0
+    assert open(p, "rb").read() == want
+    assert kp.save(p + ".gz") == 0
+    assert gzip.open(p + ".gz", "rb").read() == want
+    d = api.DescriptorStore()
+    assert d.set(g["desc_xyzsd"], g["desc_hist"], tuple(int(v) for v in g["dims"])) == 0
+    q = str(tmp_path / "desc.csv")
+    assert d.save(q) == 0
+    got = open(q, "rb").read()
+    assert len(got) == int(g["desc_csv_bytes"])
+    rows = got.split(b"\n")
+    assert rows[0] == bytes(g["desc_csv_first_row"])
+    assert (rows[-2] if rows[-1] == b"" else rows[-1]) == bytes(g["desc_csv_last_row"])
+    assert got.endswith(b"\n") == bool(g["desc_csv_ends_with_newline"])
+    assert hashlib.sha1(got).hexdigest() == str(g["desc_csv_sha1"])
+    assert d.save(q + ".gz") == 0
+    assert gzip.open(q + ".gz", "rb").read() == got
+    # the same rows through the matrix converter (sift3d_descriptor_store_to_mat_rm)
+    m = d.to_mat_rm()
+    np.testing.assert_array_equal(m[:, 3:], g["desc_hist"])
+    np.testing.assert_array_equal(m[:, :3], g["desc_xyzsd"][:, :3].astype(np.float32))
+
+
 def test_hot_path_fails_loudly_without_device(api):
     if api.device_available():
         pytest.skip("a device is present")
