@@ -29,9 +29,11 @@ sift3d_make_image(const int nx, const int ny, const int nz, const int nc);
 SIFT3D_EXPORT void
 sift3d_free_image(sift3d_image *);
 
-/* Read a NIfTI-1 file.  nifticlib is not part of this build, so -- like a
- * reference build without SIFT3D_WITH_NIFTI (sift3d/nifti.c:16-31) -- this
- * reports the missing wrapper on stderr and returns NULL.
+/* Read a single-file NIfTI-1 image (.nii, .nii.gz) with the built-in reader: the
+ * subset of nifticlib that the reference's wrapper uses (sift3d/nifti.c:52-167:
+ * dimensions, pixdim spacing, every scalar datatype, scl_slope / scl_inter).
+ * Analyze pairs (.hdr/.img) and DICOM directories are not read: NULL with a message
+ * on stderr, like a reference build without nifticlib (sift3d/nifti.c:16-31).
  * reference: sift3d/imutil.h:54-55, sift3d/imutil.c:1657-1670 */
 SIFT3D_EXPORT sift3d_image *
 sift3d_read_image(const char *path);

@@ -35,7 +35,12 @@ extern "C" {
 
 /* As sift3d_detect_keypoints (reference: sift.c:1217-1249) for a single-channel
  * nx*ny*nz float32 volume that already lives in device memory (`d_volume`), with
- * voxel spacing (ux,uy,uz).  The volume is not modified. */
+ * voxel spacing (ux,uy,uz) > 0.  The volume is not modified.
+ * Synchronisation contract: the work is issued on the detector's own stream, which is NOT
+ * ordered after other streams -- the caller makes sure the producer of d_volume has finished
+ * (e.g. torch.cuda.synchronize(), or an event wait) before calling; on return the results are
+ * complete (the call synchronises its stream).  A detector belongs to the HIP device that was
+ * current at its first detect call. */
 SIFT3D_AMD_API int
 sift3d_amd_detect_keypoints_device(sift3d_detector *det, const float *d_volume,
                                    int nx, int ny, int nz, double ux, double uy,
@@ -113,6 +118,7 @@ SIFT3D_AMD_API const char *sift3d_amd_version(void);
 /* ------------------------------------------------------------------------ */
 SIFT3D_AMD_API int sift3d_hip_device_count(void);
 SIFT3D_AMD_API int sift3d_hip_set_device(int dev);
+SIFT3D_AMD_API int sift3d_hip_current_device(void);   /* -1 on error */
 SIFT3D_AMD_API void *sift3d_hip_malloc(size_t bytes);
 SIFT3D_AMD_API void sift3d_hip_free(void *d_ptr);
 SIFT3D_AMD_API void *sift3d_hip_host_alloc(size_t bytes); /* pinned */

@@ -109,6 +109,7 @@ struct _sift3d_detector {
     int nfilt;
     /* device state */
     void *stream, *copy_stream;
+    int device;            /* HIP device of the streams / pyramids */
     void *ev[8];
     void *ev_chunk[8];
     float *d_im, *d_tmp_a, *d_tmp_b, *d_in;
@@ -130,7 +131,7 @@ struct _sift3d_detector {
     double t[SIFT3D_AMD_NUM_TIMINGS];
 };
 
-static int g_mesh_ready = 0;
+static unsigned char g_mesh_ready[64];   /* per device: the __constant__ tables live on ONE device */
 
 static double now_s(void)
 {
@@ -729,8 +730,13 @@ static int upload_mesh(void)
         { 3, 2, 10 }, { 3, 10, 6 } };
     float rec[NFACES * SIFT3D_HIP_FACE_FLOATS];
     int i, j, k;
-    if (g_mesh_ready)
-        return SIFT3D_SUCCESS;
+    {
+        const int dev = sift3d_hip_current_device();
+        if (dev < 0 || dev >= (int)sizeof(g_mesh_ready))
+            return SIFT3D_FAILURE;
+        if (g_mesh_ready[dev])
+            return SIFT3D_SUCCESS;
+    }
     for (i = 0; i < NFACES; i++) {
         float v[3][3], a[3], b[3], n[3];
         float *r = rec + i * SIFT3D_HIP_FACE_FLOATS;
@@ -772,7 +778,7 @@ static int upload_mesh(void)
     }
     if (sift3d_hip_set_mesh(rec))
         return SIFT3D_FAILURE;
-    g_mesh_ready = 1;
+    g_mesh_ready[sift3d_hip_current_device()] = 1;
     return SIFT3D_SUCCESS;
 }
 
@@ -1103,12 +1109,20 @@ int sift3d_amd_num_candidates(const sift3d_detector *d) { return d->ncand; }
 static int ensure_device(sift3d_detector *d)
 {
     int i;
-    if (d->stream)
+    if (d->stream) {
+        /* a detector lives on the device it first ran on (its streams, pyramids, tables) */
+        if (sift3d_hip_current_device() != d->device) {
+            ERR("sift3d_amd: this detector belongs to HIP device %d, the current device is %d \n",
+                d->device, sift3d_hip_current_device());
+            return SIFT3D_FAILURE;
+        }
         return SIFT3D_SUCCESS;
+    }
     if (!sift3d_amd_device_available()) {
         ERR("sift3d_amd: no HIP device is available; this library has no CPU path \n");
         return SIFT3D_FAILURE;
     }
+    d->device = sift3d_hip_current_device();
     if (!(d->stream = sift3d_hip_stream_create()) || !(d->copy_stream = sift3d_hip_stream_create()))
         return SIFT3D_FAILURE;
     for (i = 0; i < 8; i++)
@@ -1443,6 +1457,10 @@ int sift3d_amd_detect_keypoints_device(sift3d_detector *d, const float *d_volume
 {
     if (!d || !d_volume || !store || nx < 1 || ny < 1 || nz < 1)
         return SIFT3D_FAILURE;
+    if (!(ux > 0) || !(uy > 0) || !(uz > 0)) {          /* as sift3d_amd_image_set_units */
+        ERR("sift3d_amd: voxel spacing must be positive, provided (%f, %f, %f) \n", ux, uy, uz);
+        return SIFT3D_FAILURE;
+    }
     if (ensure_device(d))
         return SIFT3D_FAILURE;
     return detect_on_device(d, d_volume, nx, ny, nz, ux, uy, uz, store);

@@ -61,6 +61,14 @@ int sift3d_hip_device_count(void)
 
 int sift3d_amd_device_available(void) { return sift3d_hip_device_count() > 0; }
 
+int sift3d_hip_current_device(void)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess)
+        return -1;
+    return dev;
+}
+
 int sift3d_hip_set_device(int dev)
 {
     HIPCHK(hipSetDevice(dev));
@@ -1695,6 +1703,11 @@ __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restric
     bounds_d(cx, rad, L.ux, L.nx, B.xs, B.xe);
     bounds_d(cy, rad, L.uy, L.ny, B.ys, B.ye);
     bounds_d(cz, rad, L.uz, L.nz_glob, B.zs, B.ze);
+    // memory safety on Z-slabs: never outside the local planes (the gradient reads z -+ 1).  A
+    // caller whose halo is thinner than the window gets wrong sums, not a fault; the slab driver
+    // sizes its halos from sigma0 / units and refuses configurations that do not fit.
+    B.zs = max(B.zs, L.z_off + 1);
+    B.ze = min(B.ze, L.z_off + L.nz - 2);
     double dacc = 0.0; // lanes 0..5: A00 A01 A02 A11 A12 A22
     float facc = 0.0f; // lanes 6..8: vd_win x y z
     const double *tdp = td[lane < 6 ? lane : 0];
@@ -1994,6 +2007,9 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     bounds_f(K.cx, rad, L.ux, L.nx, B.xs, B.xe);
     bounds_f(K.cy, rad, L.uy, L.ny, B.ys, B.ye);
     bounds_f(K.cz, rad, L.uz, L.nz_glob, B.zs, B.ze);
+    // memory safety on Z-slabs: never outside the local planes (see k_orient)
+    B.zs = max(B.zs, L.z_off + 1);
+    B.ze = min(B.ze, L.z_off + L.nz - 2);
     // phase B roles: each half-wave commits one voxel per round; its lanes 0..23 are the
     // (trilinear cell corner, face vertex) pairs of that voxel.  Lanes 24..31 repeat lane 0's
     // work (same address, same value: harmless), which keeps the commit free of predication.

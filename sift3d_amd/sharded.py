@@ -36,15 +36,19 @@ KP_DTYPE = np.dtype([("R", "f4", (3, 3)), ("xd", "f8"), ("yd", "f8"), ("zd", "f8
 GKP_DTYPE = np.dtype([("o", "i4"), ("s", "i4"), ("x", "i4"), ("y", "i4"), ("z", "i4"),
                       ("R", "f4", (9,))])
 
-WINDOW_HALO = 40   # planes: ceil(2 * 7.0711 * 1.6 * 2^(2/3)) + 1 (gradient) + slack
-MIN_SLAB = 48      # a sharded octave keeps at least this many planes per rank
+# Defaults (sigma0 1.6, K 3, unit spacing): the descriptor window of the last keypoint level
+# reaches ceil(2 * 7.0711 * 1.6 * 2^(2/3)) + 2 = 38 planes; a sharded octave keeps at least the
+# halo + 8 planes per rank.  ShardedSift3D derives both from its own sigma0 / units / K.
+WINDOW_HALO = 40
+MIN_SLAB = 48
 
 
 class Geometry:
     """Octave / slab bookkeeping (pure Python)."""
 
-    def __init__(self, nx, ny, nz, world, num_kp_levels=3):
+    def __init__(self, nx, ny, nz, world, num_kp_levels=3, min_slab=MIN_SLAB):
         self.world = world
+        self.min_slab = int(min_slab)
         mn = min(nx, ny, nz)
         last = int(math.log2(mn)) - 3                      # sift.c:442-444
         if last < 0:
@@ -62,7 +66,7 @@ class Geometry:
         self.o_shard = 0
         if world > 1:
             while (self.o_shard < self.num_octaves and
-                   (self.dims[self.o_shard][2] // world) >= MIN_SLAB):
+                   (self.dims[self.o_shard][2] // world) >= self.min_slab):
                 self.o_shard += 1
         # slab bounds at octave 0: multiples of 2^o_shard, so that every slab boundary is EVEN in
         # every sharded octave and im_downsample_2x (dst z <- src 2z) never needs a neighbour's
@@ -267,16 +271,35 @@ class ShardedSift3D:
         self.cuboid = bool(cuboid_extrema)   # CUBOID_EXTREMA (sift.c:24) as a run-time option
         self.sigma_n, self.sigma0 = float(sigma_n), float(sigma0)
         self.units = tuple(float(u) for u in units)
-        self.g = Geometry(nx, ny, nz, self.world, num_kp_levels)
-        g = self.g
-        if self._scale(0, -1) < self.sigma_n:              # imutil.c:1582-1588
+        if min(self.units) <= 0:
+            raise ValueError("voxel spacing must be positive")
+        K = int(num_kp_levels)
+        if self.sigma0 * math.pow(2.0, -1.0 / K) < self.sigma_n:       # imutil.c:1582-1588
             raise ValueError("sigma_n too large for these settings")
         # filter bank (make_gss, imutil.c:1360-1409)
         self.filters = []
-        for i in range(g.ngl):
-            s_cur = self.sigma_n if i == 0 else self._scale(0, i - 2)
-            s_next = self._scale(0, i - 1)
+        for i in range(K + 3):
+            s_cur = self.sigma_n if i == 0 else self.sigma0 * math.pow(2.0, (i - 2) / K)
+            s_next = self.sigma0 * math.pow(2.0, (i - 1) / K)
             self.filters.append(self.be.gauss_filter(math.sqrt(s_next * s_next - s_cur * s_cur)))
+        # Halo planes a slab needs from its neighbours, in LEVEL planes (the same number in every
+        # octave: scale and spacing double together):
+        #   window: the descriptor window of Gaussian level s (keypoint level s - 1) reaches
+        #           rad = 2 * 7.0711 * sd (sift.c:1453-1454) = 14.1422 * sigma0 * 2^((s-1)/K) / uz
+        #           planes, + 1 for the gradient, + 1 for ceil of a fractional centre;
+        #   blur:   the z pass reads ceil(hw * unit_factor) + 1 planes (imutil.c:756-757), most at
+        #           octave 0 where unit_factor = 1 / uz.
+        uz = self.units[2]
+        self.win_reach = [int(math.ceil(14.1422 * self.sigma0 * 2.0 ** ((s - 1) / K) / uz)) + 2
+                          if 1 <= s <= K else 1 for s in range(K + 3)]
+        hw_max = max(len(f) // 2 for f in self.filters)
+        blur_reach = int(math.ceil(hw_max * float(np.float32(1.0 / uz)))) + 1
+        self.halo = max(max(self.win_reach), blur_reach)
+        if self.halo > 500:
+            raise ValueError("sigma0 / units give a %d-plane window: beyond what the window kernels "
+                             "address (1023 voxels per axis)" % self.halo)
+        self.g = Geometry(nx, ny, nz, self.world, num_kp_levels, min_slab=self.halo + 8)
+        g = self.g
         self._alloc()
         self.t_pyr = 0.0
         self._table = None
@@ -299,7 +322,7 @@ class ShardedSift3D:
             nx, ny, nz = g.dims[o]
             if g.sharded(o):
                 z0, z1 = g.own(o, r)
-                off, hi = max(0, z0 - WINDOW_HALO), min(nz, z1 + WINDOW_HALO)
+                off, hi = max(0, z0 - self.halo), min(nz, z1 + self.halo)
             else:
                 z0, z1 = g.own(o, r)                       # work split of a replicated level
                 off, hi = 0, nz
@@ -347,6 +370,9 @@ class ShardedSift3D:
             return
         r, t = self.rank, lv.t
         a, b = lv.own()
+        if h > self.halo or h > b - a:
+            raise ValueError("a %d-plane halo does not fit slabs of %d planes with %d halo planes"
+                             % (h, b - a, self.halo))
         sends, recvs = [], []
         if r > 0 and lv.z0 > 0:
             sends.append((t[a:a + h], r - 1))
@@ -543,12 +569,7 @@ class ShardedSift3D:
                 # keypoint level s-1 (Gaussian index s): the descriptor window reaches
                 # 2 * 7.0711 * sigma0 * 2^((s-1)/K) / uz planes (sift.c:1453-1455) + 1 for the
                 # gradient; the other levels only feed the DoG / extrema neighbours
-                if 1 <= s <= g.K:
-                    need = int(math.ceil(14.1422 * self.sigma0 * 2.0 ** ((s - 1) / g.K) /
-                                         self.units[2])) + 2
-                    self._halo(self.G[o][s], min(need, WINDOW_HALO))
-                else:
-                    self._halo(self.G[o][s], 1)
+                self._halo(self.G[o][s], self.win_reach[s])
         # build_dog (sift.c:713-732) + dogmax (sift.c:821-826)
         scal = []
         stack = getattr(be, "dog_stack", None)

@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, dims, outdir, cuboid=False):
+def _worker(rank, world, port, dims, outdir, cuboid=False, sigma0=1.6, units=(1.0, 1.0, 1.0)):
     sys.path.insert(0, ROOT)
     os.environ["OMP_NUM_THREADS"] = "2"
     import torch
@@ -40,7 +40,7 @@ def _worker(rank, world, port, dims, outdir, cuboid=False):
         nx, ny, nz = dims
         vol = so.synth_survey(dims, nblob=int(200 * nx * ny * nz / 64 ** 3))
         job = sharded.ShardedSift3D(nx, ny, nz, dist.group.WORLD, backend=OracleBackend(),
-                                    cuboid_extrema=cuboid)
+                                    cuboid_extrema=cuboid, sigma0=sigma0, units=units)
         z0, z1 = job.in_own
         job.set_local_volume(vol[z0:z1])
         kp = job.detect()
@@ -48,7 +48,7 @@ def _worker(rank, world, port, dims, outdir, cuboid=False):
         mat = job.gather_descriptors()
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), kp=kp, idx=idx, mat=mat,
                  ncand=job.ncand, o_shard=job.g.o_shard, bounds=np.array(job.g.b0),
-                 num_octaves=job.g.num_octaves)
+                 num_octaves=job.g.num_octaves, halo=job.halo)
     finally:
         dist.destroy_process_group()
 
@@ -91,6 +91,41 @@ def test_sharded_equals_single(world, dims, cuboid):
         assert all(v % (1 << int(res[0]["o_shard"])) == 0 for v in b[:-1])
     else:
         assert int(res[0]["o_shard"]) == 0           # tiny volume: replicated, work split only
+
+
+def test_sharded_wide_windows_equal_single():
+    """sigma0 = 2.0 and a 0.7 voxel spacing along z: the descriptor window reaches
+    ceil(14.1422 * 2.0 * 2^(2/3) / 0.7) + 2 = 67 planes, far beyond the default 40-plane halo.
+    The driver must size its halos (and its minimum slab) from sigma0 / units, and the result
+    must still equal the single-process run bit for bit."""
+    import torch.multiprocessing as mp
+    from oracle import sift3d_oracle as so
+    dims, world, sigma0, units = (28, 30, 320), 2, 2.0, (1.0, 1.2, 0.7)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), dims, d, False, sigma0, units), nprocs=world,
+                 join=True)
+        res = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(world)]
+    nx, ny, nz = dims
+    vol = so.synth_survey(dims, nblob=int(200 * nx * ny * nz / 64 ** 3))
+    o = so.Oracle(sigma0=sigma0)
+    assert o.detect(vol, units) == 0 and o.describe() == 0
+    ok, want_mat = o.keypoints(), o.desc_mat()
+    assert len(ok) > 5
+    for g in res:
+        assert int(g["halo"]) == 67 and int(g["o_shard"]) >= 1
+        assert int(g["ncand"]) == len(o.candidates())
+        for f in ("o", "s", "xd", "yd", "zd", "sd", "strength", "R"):
+            np.testing.assert_array_equal(g["kp"][f], ok[f], err_msg=f)
+        np.testing.assert_array_equal(g["mat"], want_mat)
+
+
+def test_sharded_refuses_what_does_not_fit():
+    from sift3d_amd.sharded import ShardedSift3D
+    from tests.cpu_backend import OracleBackend
+    with pytest.raises(ValueError):
+        ShardedSift3D(32, 32, 64, None, backend=OracleBackend(), units=(1.0, 1.0, 0.0))
+    with pytest.raises(ValueError):                       # a 1400-plane window
+        ShardedSift3D(32, 32, 64, None, backend=OracleBackend(), sigma0=40.0)
 
 
 def test_geometry_alignment():
