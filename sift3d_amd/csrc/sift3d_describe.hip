@@ -1,0 +1,662 @@
+// sift3d_describe.hip -- the descriptor kernel (k_describe), the icosahedron tables it uses and
+// their C entries (sift3d_hip_set_mesh, sift3d_hip_describe).
+//
+// A translation unit of its own because it is compiled with -fno-slp-vectorize, like
+// sift3d_fir_yz.hip: packed v_pk_* arithmetic gains nothing on gfx950 and costs this kernel
+// registers and ~7 % of its time.  Numerical contract (no FMA contraction) and citation style
+// as in sift3d_kernels.hip.
+#include "sift3d_kernels_common.h"
+#include "sift3d_math.h"
+
+#include <cstdlib>
+
+// ---------------------------------------------------------------------------------------
+// extract_descrip  (sift.c:1442-1536): one wave per keypoint.
+//
+// Scan    (64 voxels in parallel): exact window test, survivors stream-compacted into an LDS
+//         queue so that the expensive phases always run on 64 window voxels.
+// Phase A (one lane per voxel): gradient, Gaussian weight, rotation into keypoint space,
+//         icosahedron face + barycentrics, the eight trilinear cell weights -- the reference's
+//         float expressions, so every per-voxel DECISION (window, |g| threshold, face, skipped
+//         corner) and every per-voxel VALUE is the reference's bit for bit.
+// Phase B (commit): a voxel adds mag*w_cell*bary_j to 24 distinct bins (8 cells x 3 face
+//         vertices), which 24 lanes do as ONE plain LDS read-modify-write.  The two half-waves
+//         commit two voxels per round into two PRIVATE histograms, which are added at the end.
+//
+// Accumulation order: the reference adds voxels in scan order (z, y, x).  Here every 64-voxel
+// batch is cut into four runs of 16 consecutive voxels; half-wave 0 adds runs 0 and 2 to its
+// histogram, half-wave 1 runs 1 and 3 to its own, and the two partial histograms are merged as
+// h0 + h1.  The order is fixed by the keypoint alone (not by timing), so results are bitwise
+// reproducible run to run; against the reference they differ by summation order only: the terms
+// of a bin are >= -1e-6 * |term|, so the relative error of a bin is a few float ulps
+// (BASELINE's bar: 1e-5 relative).
+// LDS float atomics are not an option on gfx950: ds_add_f32 retires ~0.3 lane-adds/clk/CU
+// (measured, scratch microbenchmark), 20x slower than the read-modify-write below.
+// ---------------------------------------------------------------------------------------
+struct FaceRec {
+    float v0[3], e1[3], e2[3], t[3], q[3], e2q, idx[3];
+};
+static_assert(sizeof(FaceRec) == SIFT3D_HIP_FACE_FLOATS * 4, "face record layout");
+
+// per-face constants as the kernel wants them: e1, e2, t, q, e2.q, packed bin offsets (+2 pad)
+__constant__ float c_face16[20 * 16];
+__constant__ int c_bin_off[12];    // LDS offset of each vertex's 64-cell block (see k_describe)
+// face that contains a direction, by sign octant (bit 0/1/2 = x/y/z negative) and position
+// relative to the octant's central face: see icos_guess
+__constant__ int c_oct_face[32];
+
+constexpr int DQ = 256; // compaction queue length (power of two, >= 63 + 2 * 64)
+// LDS histogram: bin (cell, vertex) lives at c_bin_off[vertex] + cell, cell = ix + 4*iy + 16*iz.
+// The offsets are 64*rank + {0, 8, 18, 26}[colour] for a proper 4-colouring of the
+// icosahedron's vertices, which puts the 24 bins of any voxel (8 neighbouring cells x the 3
+// vertices of a face) on 24 different banks of the 32 that ds_read_b32/ds_write_b32 use.
+constexpr int HIST_LDS = 800;
+// Phase A -> phase B records, field-major: row f holds field f of half a batch (32 voxels; the
+// records go through LDS half a batch at a time: LDS capacity is what limits the waves per CU).
+// Rows are 36 floats apart: the eight rows that the 24 committer lanes of a half-wave read with
+// ds_read_b128 (four voxels at a time) fall on disjoint bank quads.
+constexpr int RROW = 36;
+
+#ifdef SIFT3D_AMD_DIAG
+#define DESC_ABLATE_ARG , int ablate
+#define DESC_ABLATE(bit) (ablate & (bit))
+#else
+#define DESC_ABLATE_ARG
+#define DESC_ABLATE(bit) false
+#endif
+
+// Lanes of ONE wave exchanging data through LDS: the DS operations of a wave execute in issue
+// order, so a read issued after a write sees it -- no s_waitcnt, no s_barrier; the fences only
+// keep the compiler from moving LDS accesses across the hand-over point.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// cart2bary + the acceptance test of icos_hist_bin (sift.c:276-297, 1268-1286) for one face,
+// the reference's float expressions.  fr: the face's 16-float record (LDS).
+__device__ __forceinline__ bool face_eval(const float4 *__restrict__ fr, float rx, float ry, float rz,
+                                          float &xb, float &yb, float &zb, int &fi)
+{
+    const float4 A0 = fr[0], A1 = fr[1], A2 = fr[2], A3 = fr[3];
+    // e1 = A0.xyz, e2 = (A0.w, A1.x, A1.y), t = (A1.z, A1.w, A2.x),
+    // q = (A2.y, A2.z, A2.w), e2.q = A3.x, bin offsets = A3.y
+    const float px = ry * A1.y - rz * A1.x;        // p = g x e2, sift.c:278
+    const float py = rz * A0.w - rx * A1.y;
+    const float pz = rx * A1.x - ry * A0.w;
+    const float det = A0.x * px + A0.y * py + A0.z * pz;
+    const float di = 1.0f / det;
+    yb = di * (A1.z * px + A1.w * py + A2.x * pz);
+    zb = di * (rx * A2.y + ry * A2.z + rz * A2.w);
+    xb = 1.0f - yb - zb;
+    const float kk = A3.x * di;
+    fi = __float_as_int(A3.y);
+    return !(fabsf(det) < 1.1920928955078125e-06f) &&            // sift.c:282
+           !(xb < -1.1920928955078125e-06f || yb < -1.1920928955078125e-06f ||
+             zb < -1.1920928955078125e-06f || kk < 0);            // sift.c:1277-1279
+}
+
+// A GUESS of the face a direction falls in (no decision rests on it: the caller verifies the
+// guess with face_eval and falls back to the reference's full face scan).  The vertex set
+// (0,+-1,+-g), (+-1,+-g,0), (+-g,0,+-1) is symmetric under sign flips, so the direction is
+// reflected into the positive octant, which holds the face C = {(0,1,g), (1,g,0), (g,0,1)}
+// and one third each of the three faces across C's edges; t1..t3 are the signed distances to
+// the planes through the origin and C's edges.
+__device__ __forceinline__ int icos_guess(float rx, float ry, float rz)
+{
+    const float g = 1.6180339887f, g2 = 2.6180339887f;
+    const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
+    const float t1 = ax + g2 * ay - g * az;      // edge (0,1,g)-(g,0,1), beyond: face with (0,-1,g)
+    const float t2 = ay + g2 * az - g * ax;      // edge (g,0,1)-(1,g,0), beyond: face with (g,0,-1)
+    const float t3 = az + g2 * ax - g * ay;      // edge (1,g,0)-(0,1,g), beyond: face with (-1,g,0)
+    // (integer arithmetic, not nested selects: the compiler turns those into branches, and the
+    // caller wants this in one basic block with the commit chain)
+    const int n1 = t1 < 0.0f, n2 = t2 < 0.0f, n3 = t3 < 0.0f;
+    const int cls = n1 + (1 - n1) * (2 * n2 + (1 - n2) * 3 * n3);
+    return cls * 8 + (int)(rx < 0.0f) + 2 * (int)(ry < 0.0f) + 4 * (int)(rz < 0.0f);
+}
+
+constexpr int DWAVES = 4;   // keypoints (waves) per workgroup; they share the read-only tables
+
+__global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level *__restrict__ levels,
+                                                 const sift3d_hip_kp *__restrict__ kps, uint32_t n,
+                                                 float *__restrict__ out DESC_ABLATE_ARG)
+{
+    // per wave: 2 * 3200 + 2016 + 1024 B; per workgroup 39.4 KB -> four workgroups = 16 waves per CU
+    __shared__ float hist_[DWAVES][2 * HIST_LDS];   // one private histogram per half-wave
+    __shared__ __attribute__((aligned(16))) float mw_[DWAVES][8][RROW]; // mag * trilinear weight of the eight cells
+    __shared__ __attribute__((aligned(16))) float bw_[DWAVES][3][RROW]; // barycentric weights
+    __shared__ __attribute__((aligned(16))) int ab_[DWAVES][3][RROW];   // byte address of bin (base cell, face vertex j)
+    __shared__ int queue_[DWAVES][DQ];   // xx | yy<<10 | zz<<20, window-relative, in scan order
+    __shared__ __attribute__((aligned(16))) float sface[20 * 16]; // c_face16 (per-lane face index)
+    __shared__ int soct[32];      // c_oct_face
+    __shared__ uint64_t sexp[32]; // s3d_exp2_tab (per-lane index)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    float *const hist = hist_[wv];
+    float(*const mw)[RROW] = mw_[wv];
+    float(*const bw)[RROW] = bw_[wv];
+    int(*const ab)[RROW] = ab_[wv];
+    int *const queue = queue_[wv];
+    for (int i = threadIdx.x; i < 20 * 16; i += 64 * DWAVES)
+        sface[i] = c_face16[i];
+    if (threadIdx.x < 32) {
+        soct[threadIdx.x] = c_oct_face[threadIdx.x];
+        sexp[threadIdx.x] = s3d_exp2_tab[threadIdx.x];
+    }
+    for (int i = lane; i < 2 * HIST_LDS; i += 64)
+        hist[i] = 0.0f;
+    __syncthreads();              // the only workgroup barrier: from here on the waves are independent
+    const uint32_t ki = blockIdx.x * DWAVES + wv;
+    if (ki >= n)
+        return;
+    const sift3d_hip_kp K = kps[ki];
+    const sift3d_hip_level L = levels[K.level];
+    const uint32_t orow = K.row1 ? K.row1 - 1 : ki;   // output row (launch order may differ)
+
+    const float sigma = (float)(K.sd * 7.071067812);                  // sift.c:1453
+    const float rad = (float)(2.0 * (double)sigma);                   // sift.c:1454
+    const float half_w = (float)((double)rad / 1.4142135623730951);   // / sqrt(2), sift.c:1455
+    const float desc_w = 2.0f * half_w;
+    const float hist_w = desc_w / 4.0f;                               // / NHIST_PER_DIM
+    const float bin_f = 1.0f / hist_w;
+    const float rad2 = rad * rad;
+    const float sig2 = sigma * sigma;
+    const float *R = K.R; // Rt[i][j] = R[j][i]
+    const float iux = 1.0f / L.ux, iuy = 1.0f / L.uy, iuz = 1.0f / L.uz;
+    Box B;
+    bounds_f(K.cx, rad, L.ux, L.nx, B.xs, B.xe);
+    bounds_f(K.cy, rad, L.uy, L.ny, B.ys, B.ye);
+    bounds_f(K.cz, rad, L.uz, L.nz_glob, B.zs, B.ze);
+    // memory safety on Z-slabs: never outside the local planes (see k_orient)
+    B.zs = max(B.zs, L.z_off + 1);
+    B.ze = min(B.ze, L.z_off + L.nz - 2);
+    // phase B roles: each half-wave commits one voxel per round; its lanes 0..23 are the
+    // (trilinear cell corner, face vertex) pairs of that voxel.  Lanes 24..31 repeat lane 0's
+    // work (same address, same value: harmless), which keeps the commit free of predication.
+    const int half = lane >> 5, l5 = lane & 31;
+    const int pc = l5 < 24 ? l5 / 3 : 0, pj = l5 < 24 ? l5 - 3 * pc : 0;
+    const int pdx = (pc >> 2) & 1, pdy = (pc >> 1) & 1, pdz = pc & 1;
+    // byte offset of this lane's cell corner, in this half-wave's histogram
+    const int coff4 = 4 * (pdx + 4 * pdy + 16 * pdz) + half * (HIST_LDS * 4);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    uint32_t qhead = 0, qtail = 0; // wave-uniform
+    bool pend = false;             // registers pv/ppk hold the batch starting at qhead
+
+    // Window voxel -> (window test, spatial bins).  Same float expressions in the scan and
+    // in the batch, so both see identical values.
+    auto window = [&](int x, int y, int z, float &sq, float &vbx, float &vby, float &vbz) -> bool {
+        const float dx = ((float)x - K.cx) * L.ux;                 // sift.c:102-104
+        const float dy = ((float)y - K.cy) * L.uy;
+        const float dz = ((float)z - K.cz) * L.uz;
+        sq = dx * dx + dy * dy + dz * dz;
+        // vkp = Rt * vim (immacros.h:328-340)
+        const float kx = R[0] * dx + R[3] * dy + R[6] * dz;
+        const float ky = R[1] * dx + R[4] * dy + R[7] * dz;
+        const float kz = R[2] * dx + R[5] * dy + R[8] * dz;
+        vbx = (kx + half_w) * bin_f;                               // sift.c:1483-1485
+        vby = (ky + half_w) * bin_f;
+        vbz = (kz + half_w) * bin_f;
+        // sift.c:106 (float) and sift.c:1488-1492: none of vb* < 0, none >= 4 (finite inputs)
+        const float lo = fminf(fminf(vbx, vby), vbz), hi = fmaxf(fmaxf(vbx, vby), vbz);
+        return !(sq > rad2) && !(lo < 0.0f) && !(hi >= 4.0f);
+    };
+
+    // One batch: the next `cnt` (<= 64) queued voxels, in scan order.
+    // The six gradient samples of a batch are fetched one batch ahead (registers pv/ppk), so
+    // their HBM/L2 latency overlaps the previous batch's binning and commit.
+    float pv[7] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    int ppk = 0;
+    // level samples are read through a global-address-space pointer (the pointer comes out of a
+    // table in memory, which would otherwise make these flat loads); nx*ny < 2^31
+    typedef const float __attribute__((address_space(1))) *gfloat_p;
+    const gfloat_p gdata = (gfloat_p)L.data;
+    const uint32_t ys32 = (uint32_t)L.nx, zs32 = (uint32_t)L.nx * (uint32_t)L.ny;
+    // Sample requests of a batch, branch-free: lanes beyond cnt keep their previous (valid) voxel
+    // and simply fetch it again.  The Gaussian weight (prefetch_weight) only needs the
+    // coordinates; it is evaluated later, inside the commit chain of the previous batch.
+    auto prefetch_loads = [&](uint32_t start, int cnt) {
+        const int qv = queue[(start + lane) & (DQ - 1)];
+        ppk = lane < cnt ? qv : ppk;
+        const int x = B.xs + (ppk & 1023), y = B.ys + ((ppk >> 10) & 1023),
+                  zl = B.zs + (ppk >> 20) - L.z_off;
+        const gfloat_p p = gdata + ((uint64_t)zs32 * (uint32_t)zl + (uint32_t)(x + (int)ys32 * y));
+        pv[0] = p[1]; pv[1] = *(p - 1); pv[2] = p[ys32]; pv[3] = *(p - ys32);
+        pv[4] = p[zs32]; pv[5] = *(p - zs32);
+    };
+    auto prefetch_weight = [&]() {
+        const int x = B.xs + (ppk & 1023), y = B.ys + ((ppk >> 10) & 1023);
+        const float dx = ((float)x - K.cx) * L.ux;                 // sift.c:102-104
+        const float dy = ((float)y - K.cy) * L.uy;
+        const float dz = ((float)(B.zs + (ppk >> 20)) - K.cz) * L.uz;
+        // (queued voxels passed the window test: the argument lies in [-2, 0])
+        pv[6] = s3d_expf_in_range(-0.5f * (dx * dx + dy * dy + dz * dz) / sig2, sexp); // sift.c:1498
+    };
+    auto prefetch = [&](uint32_t start, int cnt) {
+        prefetch_loads(start, cnt);
+        prefetch_weight();
+    };
+
+    // Records of the batch that is being committed, one voxel per lane: mag * trilinear weight
+    // of the eight cells, the three barycentric weights, the three bin addresses.  Empty records
+    // (zero weight, bin address 0) add 0 to a valid bin.
+    float rmw[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, rbw[3] = { 0.f, 0.f, 0.f };
+    int rab[3] = { 0, 0, 0 };
+    // One commit pass: the records of half a batch (voxels 32 * pass .. 32 * pass + 31) go to
+    // LDS, field-major, then round u adds voxel u of them (half-wave 0) and voxel 16 + u
+    // (half-wave 1), each into its half-wave's own histogram.  The 24 lanes of a voxel own 24
+    // distinct bins (8 cells x 3 face vertices), so the voxel's adds are ONE plain LDS
+    // read-modify-write; the DS operations of a wave execute in issue order, so round u + 1
+    // sees round u's sums.  (Reading round u + 1's bins before round u's sums are written is
+    // not an option: a bin of round u + 1 is usually a bin that ANOTHER lane writes in round
+    // u.)  The chain of dependent LDS round trips is the longest latency of the kernel and needs
+    // almost no VALU, so each pass is issued in one basic block with half of the arithmetic of
+    // the NEXT batch (see batch()), which the scheduler interleaves with it.  Records of four
+    // rounds are read with three 16-byte loads, one chunk ahead.
+    auto commit_write = [&](int pass) {
+        if (half == pass) {
+#pragma unroll
+            for (int c = 0; c < 8; c++)
+                mw[c][l5] = rmw[c];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                bw[j][l5] = rbw[j];
+                ab[j][l5] = rab[j];
+            }
+        }
+        wave_sync();
+    };
+    auto commit_rounds = [&]() {
+        if (DESC_ABLATE(1)) return;
+        const int hb = half * 16;
+        int4 mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb]);
+        float4 mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb]);
+        float4 bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int mb[4] = { mb4.x, mb4.y, mb4.z, mb4.w };
+            const float mv[4] = { mw4.x, mw4.y, mw4.z, mw4.w }, bv[4] = { bw4.x, bw4.y, bw4.z, bw4.w };
+            if (c < 3) {
+                mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb + 4 * c + 4]);
+                mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb + 4 * c + 4]);
+                bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb + 4 * c + 4]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float *bin = reinterpret_cast<float *>(reinterpret_cast<char *>(hist) + (mb[u] + coff4));
+                const float val = mv[u] * bv[u];                               // sift.c:1371-1373
+                *bin = *bin + val;
+            }
+        }
+    };
+    // One batch: phase A of `cnt` (<= 64) voxels whose samples were fetched one batch ago (cv,
+    // pk), overlapped with the two commit passes of the previous batch (records in rmw/rbw/rab)
+    // and with the sample requests of the next one (ncnt voxels from queue position nstart;
+    // ncnt may be 0); then this batch's records take the previous one's place.
+    auto batch = [&](int cnt, const float *cv, int pk, uint32_t nstart, int ncnt) {
+        prefetch_loads(nstart, ncnt);
+        if (DESC_ABLATE(2)) { prefetch_weight(); return; }
+        commit_write(0);
+        // ---- basic block 1: commit rounds of voxels 0..31  ||  window, gradient, face
+        commit_rounds();
+        // (lanes beyond cnt compute on stale -- finite -- values and are discarded below)
+        const int x = B.xs + (pk & 1023), y = B.ys + ((pk >> 10) & 1023), z = B.zs + (pk >> 20);
+        float sq, vbx, vby, vbz;
+        window(x, y, z, sq, vbx, vby, vbz);
+        // IM_GET_GRAD_ISO (sift.c:140-145, immacros.h:105-111)
+        float gx = 0.5f * (cv[0] - cv[1]), gy = 0.5f * (cv[2] - cv[3]), gz = 0.5f * (cv[4] - cv[5]);
+        gx *= iux;
+        gy *= iuy;
+        gz *= iuz;
+        const float w = cv[6];                                 // sift.c:1498, see prefetch_weight
+        gx = gx * w; gy = gy * w; gz = gz * w;
+        const float rx = R[0] * gx + R[3] * gy + R[6] * gz;    // sift.c:1502
+        const float ry = R[1] * gx + R[4] * gy + R[7] * gz;
+        const float rz = R[2] * gx + R[5] * gy + R[8] * gz;
+        const float m2 = rx * rx + ry * ry + rz * rz;
+        const bool live = lane < cnt && !(m2 < 1.1920928955078125e-06f);   // sift.c:1264
+        // icos_hist_bin (sift.c:1268-1286): the first face in table order whose barycentrics
+        // are >= -eps wins.  A face other than the one the ray really crosses can only pass
+        // if the ray misses it by ~eps, i.e. if the ray is within ~eps of an edge of its own
+        // face.  So: guess the face, evaluate it with cart2bary's arithmetic, and accept it
+        // when it passes with all barycentrics > 2e-5 (then every other face fails by a wide
+        // margin and the first match is unique); anything else -- ~1e-4 of the voxels --
+        // takes the reference's scan over all 20 faces.
+        int fidx = 0;
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        const int f0 = soct[icos_guess(rx, ry, rz)];
+        bool found = face_eval(reinterpret_cast<const float4 *>(sface) + f0 * 4, rx, ry, rz, b0, b1,
+                               b2, fidx) &&
+                     fminf(b0, fminf(b1, b2)) > 2e-5f;
+        commit_write(1);
+        // ---- basic block 2: commit rounds of voxels 32..63  ||  cell weights, next batch's
+        // Gaussian weights
+        commit_rounds();
+        prefetch_weight();
+        // trilinear cell weights (sift.c:1318-1320, 1361-1363): weight = wx * wy * wz,
+        // value = mag * weight * bary.  A corner beyond the last cell is skipped by the
+        // reference (sift.c:1349-1352).  The commit below is free of predication -- all 24 lanes
+        // of a voxel always read-modify-write -- so the 2x2x2 block of cells is shifted to stay
+        // inside the grid instead: on an axis where the base cell is the last one (index 3) the
+        // block covers cells {2, 3}, cell 3 keeps its weight 1 - f and cell 2 gets weight 0.
+        // The 24 bins stay distinct and valid; adding mag * 0 * bary = +-0 changes nothing.
+        const float mag = sqrtf(m2);                           // sift.c:1331
+        const float fx = vbx - floorf(vbx);
+        const float fy = vby - floorf(vby);
+        const float fz = vbz - floorf(vbz);
+        const int ix = (int)vbx, iy = (int)vby, iz = (int)vbz;
+        const bool lx = ix >= 3, ly = iy >= 3, lz = iz >= 3;
+        const float ax[2] = { lx ? 0.0f : 1.0f - fx, lx ? 1.0f - fx : fx },
+                    ay[2] = { ly ? 0.0f : 1.0f - fy, ly ? 1.0f - fy : fy },
+                    az[2] = { lz ? 0.0f : 1.0f - fz, lz ? 1.0f - fz : fz };
+        float mwv[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float wt = ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1];
+            mwv[c] = mag * wt;
+        }
+        // (stale lanes may hold any coordinates: keep their cell inside the grid as well)
+        const int cell4 = 4 * (min(max(ix, 0), 2) + 4 * min(max(iy, 0), 2) + 16 * min(max(iz, 0), 2));
+        if (__builtin_expect(__ballot(live && !found) != 0ull, 0)) {
+            bool open = live && !found;
+#pragma unroll 1
+            for (int f = 0; f < 20; f++) {
+                float xb, yb, zb;
+                int fi;
+                const bool hit = face_eval(reinterpret_cast<const float4 *>(sface) + f * 4, rx,
+                                           ry, rz, xb, yb, zb, fi);
+                if (open && hit) {
+                    b0 = xb; b1 = yb; b2 = zb; fidx = fi;
+                    found = true;
+                    open = false;
+                }
+                if (__ballot(open) == 0ull)
+                    break;
+            }
+        }
+        // this batch's records (voxels without a contribution: zero weights, bin address 0)
+        const bool ok = live && found;
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            rmw[c] = ok ? mwv[c] : 0.0f;
+        rbw[0] = ok ? b0 : 0.0f; rbw[1] = ok ? b1 : 0.0f; rbw[2] = ok ? b2 : 0.0f;   // (0 * NaN would be NaN)
+        // byte addresses of the bins (base cell, face vertex j) -- the vertices addressed
+        // through the UNSWAPPED idx[] of the face (quirk Q1)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            rab[j] = ok ? 4 * ((fidx >> (10 * j)) & 1023) + cell4 : 0;
+    };
+
+    // The reference scans the whole bounding box of the sphere (sift.c:96-108).  Every voxel
+    // that passes the window test lies in the sphere AND in the rotated 4x4x4 cube, so each
+    // plane only needs the voxels of a (conservative: +1 voxel, +0.1 %) rectangle around the
+    // plane's disc, clipped to the cube's extent along the image axes; the exact per-voxel
+    // test decides.
+    const float cube_x = half_w * (fabsf(R[0]) + fabsf(R[1]) + fabsf(R[2])) * 1.001f;
+    const float cube_y = half_w * (fabsf(R[3]) + fabsf(R[4]) + fabsf(R[5])) * 1.001f;
+    const float cube_z = half_w * (fabsf(R[6]) + fabsf(R[7]) + fabsf(R[8])) * 1.001f;
+    const int zs = max(B.zs, (int)floorf(K.cz - cube_z / L.uz - 1.0f));
+    const int ze = min(B.ze, (int)ceilf(K.cz + cube_z / L.uz + 1.0f));
+    for (int z = zs; z <= ze; z++) {
+        const float dzp = ((float)z - K.cz) * L.uz;
+        const float rz = sqrtf(fmaxf(rad2 - dzp * dzp, 0.0f)) * 1.001f;
+        const float xr = fminf(rz, cube_x) / L.ux + 1.0f, yr = fminf(rz, cube_y) / L.uy + 1.0f;
+        const int pxs = max(B.xs, (int)floorf(K.cx - xr)), pxe = min(B.xe, (int)ceilf(K.cx + xr));
+        const int pys = max(B.ys, (int)floorf(K.cy - yr)), pye = min(B.ye, (int)ceilf(K.cy + yr));
+        const int pbx = pxe - pxs + 1, pby = pye - pys + 1;
+        const int ppl = pbx > 0 && pby > 0 ? pbx * pby : 0;
+        const int ox = pxs - B.xs, oy = pys - B.ys;
+        // (yy, xx) of this lane's voxel in the rectangle; a chunk of 64 voxels further it is
+        // (yy + q64, xx + r64), one more row if xx wraps.  Two chunks are tested per iteration
+        // (independent arithmetic: the second hides the latency of the first).
+        const int q64 = pbx > 0 ? 64 / pbx : 0, r64 = pbx > 0 ? 64 - q64 * pbx : 0;
+        int yy = pbx > 0 ? lane / pbx : 0, xx = pbx > 0 ? lane - yy * pbx : 0;
+        for (int c0 = 0; c0 < ppl; c0 += 128) {
+            int xx1 = xx + r64, yy1 = yy + q64;
+            if (xx1 >= pbx) {
+                xx1 -= pbx;
+                yy1++;
+            }
+            float sq, vbx, vby, vbz;
+            const bool in0 = window(pxs + xx, pys + yy, z, sq, vbx, vby, vbz) && c0 + lane < ppl;
+            const bool in1 = window(pxs + xx1, pys + yy1, z, sq, vbx, vby, vbz) && c0 + 64 + lane < ppl;
+            const int pk0 = (ox + xx) | ((oy + yy) << 10) | ((z - B.zs) << 20);
+            const int pk1 = (ox + xx1) | ((oy + yy1) << 10) | ((z - B.zs) << 20);
+            xx = xx1 + r64;
+            yy = yy1 + q64;
+            if (xx >= pbx) {
+                xx -= pbx;
+                yy++;
+            }
+            const unsigned long long m0 = __ballot(in0), m1 = __ballot(in1);
+            if ((m0 | m1) == 0ull)
+                continue;
+            const uint32_t n0 = (uint32_t)__popcll(m0);
+            if (in0)
+                queue[(qtail + (uint32_t)__popcll(m0 & lt_mask)) & (DQ - 1)] = pk0;
+            if (in1)
+                queue[(qtail + n0 + (uint32_t)__popcll(m1 & lt_mask)) & (DQ - 1)] = pk1;
+            qtail += n0 + (uint32_t)__popcll(m1);
+            wave_sync();
+            // A full batch leaves the queue as soon as its samples are requested (its packed
+            // coordinates travel in ppk), one batch ahead of its binning and commit
+            while (qtail - qhead >= 64) {
+                if (pend) {
+                    float cv[7];
+#pragma unroll
+                    for (int k = 0; k < 7; k++)
+                        cv[k] = pv[k];
+                    const int cpk = ppk;
+                    batch(64, cv, cpk, qhead, 64);  // the next batch's loads fly during this one
+                } else {
+                    prefetch(qhead, 64);
+                    pend = true;
+                }
+                qhead += 64;
+            }
+        }
+    }
+    {
+        int have = pend ? 64 : 0, rest = (int)(qtail - qhead);
+        if (!have && rest) {
+            prefetch(qhead, rest);
+            have = rest;
+            rest = 0;
+        }
+        while (have) {
+            float cv[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++)
+                cv[k] = pv[k];
+            const int cpk = ppk, cnt = have;
+            batch(cnt, cv, cpk, qhead, rest);
+            have = rest;
+            rest = 0;
+        }
+    }
+    // the last batch
+    commit_write(0);
+    commit_rounds();
+    commit_write(1);
+    commit_rounds();
+    wave_sync();
+    // The two half-wave histograms are merged in a fixed order, then normalize_desc -> clamp ->
+    // normalize_desc (sift.c:1402-1429, 1514-1526).  The reference sums the 768 squares in
+    // double in element order; here every lane sums its 12-13 slots and the 64 partial sums are
+    // combined by a fixed butterfly (reproducible; the double sum agrees to ~1e-16 relative).
+    const float trunc = 0.2f * 128.0f / 768.0f;                               // sift.c:45
+    for (int i = lane; i < HIST_LDS; i += 64)
+        hist[i] = hist[i] + hist[HIST_LDS + i];
+    wave_sync();
+    for (int pass = 0; pass < 2; pass++) {
+        double norm = 0.0;
+        for (int i = lane; i < HIST_LDS; i += 64) {
+            const float el = hist[i];                                         // unused slots hold 0
+            norm += (double)el * (double)el;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            norm += __shfl_xor(norm, o, 64);
+        norm = sqrt(norm) + 2.220446049250313e-16;                            // DBL_EPSILON
+        const float inv = (float)(1.0 / norm);                                // 1.0f / norm
+        wave_sync();
+        for (int i = lane; i < HIST_LDS; i += 64) {
+            float el = hist[i] * inv;
+            if (pass == 0)
+                el = el < trunc ? el : trunc;                                 // sift.c:1520
+            hist[i] = el;
+        }
+        wave_sync();
+    }
+    for (int i = lane; i < 768; i += 64)
+        out[(size_t)orow * 768 + i] = hist[c_bin_off[i % 12] + i / 12];
+}
+
+extern "C" {
+
+// host twin of face_eval's acceptance test (same float expressions; this file is compiled with
+// FP contraction off for the host as well)
+static bool host_face_pass(const float *f16, int f, const float *r)
+{
+    const float *A = f16 + f * 16;
+    const float px = r[1] * A[5] - r[2] * A[4];
+    const float py = r[2] * A[3] - r[0] * A[5];
+    const float pz = r[0] * A[4] - r[1] * A[3];
+    const float det = A[0] * px + A[1] * py + A[2] * pz;
+    if (fabsf(det) < 1.1920928955078125e-06f)
+        return false;
+    const float di = 1.0f / det;
+    const float yb = di * (A[6] * px + A[7] * py + A[8] * pz);
+    const float zb = di * (r[0] * A[9] + r[1] * A[10] + r[2] * A[11]);
+    const float xb = 1.0f - yb - zb;
+    const float kk = A[12] * di;
+    return !(xb < -1.1920928955078125e-06f || yb < -1.1920928955078125e-06f ||
+             zb < -1.1920928955078125e-06f || kk < 0);
+}
+
+int sift3d_hip_set_mesh(const float *faces)
+{
+    int idx[60], cnt[12];
+    float f16[20 * 16];
+    memset(f16, 0, sizeof(f16));
+    memset(cnt, 0, sizeof(cnt));
+    for (int f = 0; f < 20; f++) {
+        const float *r = faces + f * SIFT3D_HIP_FACE_FLOATS;
+        for (int j = 0; j < 3; j++)
+            idx[f * 3 + j] = (int)r[16 + j];
+        memcpy(f16 + f * 16, r + 3, sizeof(float) * 13); // e1, e2, t, q, e2.q
+        for (int j = 0; j < 3; j++) {
+            const int id = idx[f * 3 + j];
+            if (id < 0 || id >= 12 || cnt[id] >= 5) {
+                snprintf(g_err, sizeof(g_err), "sift3d_hip_set_mesh: malformed face table");
+                return SIFT3D_FAILURE;
+            }
+            cnt[id]++;
+        }
+    }
+    for (int v = 0; v < 12; v++)
+        if (cnt[v] != 5) {
+            snprintf(g_err, sizeof(g_err), "sift3d_hip_set_mesh: vertex %d has %d faces", v, cnt[v]);
+            return SIFT3D_FAILURE;
+        }
+    // Proper 4-colouring of the vertex graph (backtracking over 12 vertices), then the LDS
+    // offset of each vertex's 64-cell block: blocks sorted by colour, 64 floats apart, shifted
+    // by {0, 8, 18, 26} per colour -- see HIST_LDS in the kernel section.
+    int colour[12], binoff[12];
+    {
+        bool adj[12][12];
+        memset(adj, 0, sizeof(adj));
+        for (int f = 0; f < 20; f++)
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++)
+                    if (a != b)
+                        adj[idx[f * 3 + a]][idx[f * 3 + b]] = true;
+        for (int v = 0; v < 12; v++)
+            colour[v] = -1;
+        int v = 0;
+        while (v >= 0 && v < 12) {
+            int c = colour[v] + 1;
+            for (; c < 4; c++) {
+                bool clash = false;
+                for (int u = 0; u < v; u++)
+                    clash = clash || (adj[v][u] && colour[u] == c);
+                if (!clash)
+                    break;
+            }
+            if (c < 4) {
+                colour[v++] = c;
+            } else {
+                colour[v--] = -1;
+            }
+        }
+        if (v < 0) {
+            snprintf(g_err, sizeof(g_err), "sift3d_hip_set_mesh: vertex graph is not 4-colourable");
+            return SIFT3D_FAILURE;
+        }
+        static const int shift[4] = { 0, 8, 18, 26 };
+        int rank = 0;
+        for (int c = 0; c < 4; c++)
+            for (int u = 0; u < 12; u++)
+                if (colour[u] == c)
+                    binoff[u] = 64 * rank++ + shift[c];
+    }
+    for (int f = 0; f < 20; f++) {
+        // slot 13 of the face record: LDS bin offsets of the face's three UNSWAPPED vertex ids
+        // (the bins, quirk Q1), 10 bits each
+        const int packed = binoff[idx[f * 3]] | (binoff[idx[f * 3 + 1]] << 10) |
+                           (binoff[idx[f * 3 + 2]] << 20);
+        memcpy(f16 + f * 16 + 13, &packed, sizeof(int));
+    }
+    // Octant table of icos_guess: the face that holds a point well inside each of the four
+    // regions of every sign octant, found with the reference's own acceptance test.
+    int oct[32];
+    {
+        const float g = 1.6180339887f;
+        const float rep[4][3] = { { 1.0f, 1.0f, 1.0f },
+                                  { g / 3.0f, 0.05f, (2.0f * g + 1.0f) / 3.0f },
+                                  { (2.0f * g + 1.0f) / 3.0f, g / 3.0f, 0.05f },
+                                  { 0.05f, (2.0f * g + 1.0f) / 3.0f, g / 3.0f } };
+        for (int c = 0; c < 4; c++)
+            for (int o = 0; o < 8; o++) {
+                const float r[3] = { (o & 1) ? -rep[c][0] : rep[c][0], (o & 2) ? -rep[c][1] : rep[c][1],
+                                     (o & 4) ? -rep[c][2] : rep[c][2] };
+                int hit = -1;
+                for (int f = 0; f < 20 && hit < 0; f++)
+                    if (host_face_pass(f16, f, r))
+                        hit = f;
+                if (hit < 0) {
+                    snprintf(g_err, sizeof(g_err), "sift3d_hip_set_mesh: no face holds a probe direction");
+                    return SIFT3D_FAILURE;
+                }
+                oct[c * 8 + o] = hit;
+            }
+    }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_bin_off), binoff, sizeof(binoff)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_face16), f16, sizeof(f16)));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_oct_face), oct, sizeof(oct)));
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d_kp, uint32_t n,
+                        float *d_hist, void *stream)
+{
+    if (!n)
+        return SIFT3D_SUCCESS;
+#ifdef SIFT3D_AMD_DIAG
+    // diagnostic build only (wrong results): 1 skips the commit, 2 the whole batch -- used by
+    // profiles/ scripts to attribute the kernel's time to scan / per-voxel terms / commit
+    static int ablate = getenv("SIFT3D_AMD_DESC_ABLATE") ? atoi(getenv("SIFT3D_AMD_DESC_ABLATE")) : 0;
+    hipLaunchKernelGGL(k_describe, dim3((n + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
+                       (hipStream_t)stream, d_levels, d_kp, n, d_hist, ablate);
+#else
+    hipLaunchKernelGGL(k_describe, dim3((n + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
+                       (hipStream_t)stream, d_levels, d_kp, n, d_hist);
+#endif
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+} // extern "C"
