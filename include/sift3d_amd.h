@@ -114,6 +114,60 @@ SIFT3D_AMD_API int sift3d_amd_device_available(void);
 SIFT3D_AMD_API const char *sift3d_amd_version(void);
 
 /* ------------------------------------------------------------------------ */
+/* Multi-GPU: one process per GPU, the volume cut into Z-slabs               */
+/* ------------------------------------------------------------------------ */
+
+/* The three exchanges of the slab driver (sift3d_amd/csrc/sift3d_sharded.c).  All buffers are
+ * DEVICE pointers; every call is enqueued on `stream` (stream-ordered, like RCCL) or completes
+ * before returning.  A NULL send/recv pair of `halo` means "no neighbour on that side".  Return 0
+ * on success. */
+typedef struct {
+    int rank, world;
+    void *ctx;
+    /* nearest neighbours: send send_lo to rank-1 / send_hi to rank+1, receive recv_lo from
+     * rank-1 / recv_hi from rank+1, `bytes` each */
+    int (*halo)(void *ctx, const void *d_send_lo, void *d_recv_lo, const void *d_send_hi,
+                void *d_recv_hi, size_t bytes, void *stream);
+    int (*allreduce_max)(void *ctx, float *d_buf, int n, void *stream);          /* in place */
+    int (*allgather)(void *ctx, const void *d_send, void *d_recv, size_t bytes_per_rank,
+                     void *stream);                     /* d_recv: world * bytes, rank order */
+} sift3d_amd_transport;
+
+/* RCCL over xGMI (librccl is loaded at run time).  Rank 0 makes the 128-byte unique id, the
+ * application distributes it (any out-of-band channel), every rank builds its transport on its own
+ * current HIP device. */
+SIFT3D_AMD_API int sift3d_amd_rccl_unique_id(void *id128);
+SIFT3D_AMD_API int sift3d_amd_rccl_transport(sift3d_amd_transport *out, int world, int rank,
+                                             const void *id128);
+SIFT3D_AMD_API void sift3d_amd_rccl_transport_free(sift3d_amd_transport *t);
+
+/* sift3d_detect_keypoints + sift3d_extract_descriptors (sift.c:1217-1249, 1615-1635) on ONE
+ * nx*ny*nz volume cut into `world` Z-slabs; results equal the single-GPU ones bit for bit.
+ * `params` supplies thresholds and scales (NULL: defaults); only the default configuration
+ * (3 keypoint levels per octave, 8-neighbour extrema, rows of whole quads in every octave) is
+ * supported -- create returns NULL otherwise.  This rank's raw planes [z0, z1) go to the device
+ * buffer sift3d_amd_sharded_input() (x fastest, (z1 - z0) * ny * nx floats).  detect fills `kp`
+ * with the GLOBAL keypoint list on every rank; describe computes the descriptors of the
+ * keypoints this rank owns (their positions in `kp` go to own_idx, capacity kp's size). */
+typedef struct sift3d_amd_sharded sift3d_amd_sharded;
+SIFT3D_AMD_API sift3d_amd_sharded *
+sift3d_amd_sharded_create(int nx, int ny, int nz, const sift3d_amd_transport *t,
+                          const sift3d_detector *params, double ux, double uy, double uz);
+SIFT3D_AMD_API void sift3d_amd_sharded_free(sift3d_amd_sharded *);
+SIFT3D_AMD_API int sift3d_amd_sharded_own_planes(const sift3d_amd_sharded *, int *z0, int *z1);
+SIFT3D_AMD_API float *sift3d_amd_sharded_input(sift3d_amd_sharded *);
+SIFT3D_AMD_API int sift3d_amd_sharded_synth(sift3d_amd_sharded *, uint64_t seed);
+SIFT3D_AMD_API int sift3d_amd_sharded_detect(sift3d_amd_sharded *, sift3d_keypoint_store *kp);
+SIFT3D_AMD_API int sift3d_amd_sharded_describe(sift3d_amd_sharded *, const sift3d_keypoint_store *kp,
+                                               sift3d_descriptor_store *desc, int *own_idx,
+                                               int *n_own);
+SIFT3D_AMD_API int sift3d_amd_sharded_num_candidates(const sift3d_amd_sharded *);
+/* [0] Gaussian pyramid (device seconds)  [1] detect wall  [2] describe wall */
+SIFT3D_AMD_API const double *sift3d_amd_sharded_timings(const sift3d_amd_sharded *);
+SIFT3D_AMD_API int sift3d_amd_sharded_info(const sift3d_amd_sharded *, int *num_octaves, int *o_shard,
+                                           int *halo);
+
+/* ------------------------------------------------------------------------ */
 /* Device plumbing (so that the C host code needs no HIP headers)           */
 /* ------------------------------------------------------------------------ */
 SIFT3D_AMD_API int sift3d_hip_device_count(void);

@@ -1650,3 +1650,6 @@ int sift3d_amd_copy_level(const sift3d_detector *d, int which, int o, int s, flo
         return SIFT3D_FAILURE;
     return SIFT3D_SUCCESS;
 }
+
+/* the Z-slab multi-GPU driver (uses the private layouts above) */
+#include "sift3d_sharded.c"

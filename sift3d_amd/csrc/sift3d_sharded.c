@@ -1,0 +1,981 @@
+/* sift3d_sharded.c -- Z-slab multi-GPU detect + describe, host side in C (included at the end of
+ * sift3d_host.c: it uses the private store layouts).
+ *
+ * One process per GPU; the volume is cut along z into one slab per rank.  Everything that is
+ * local in z runs unchanged on the slab (x / y FIR passes, dogmax, extrema, down-sampling on
+ * 2^k-aligned slab boundaries); exactly three kinds of exchange cross ranks, all through a small
+ * transport vtable (sift3d_amd_transport: RCCL send/recv, all-reduce, all-gather over xGMI in
+ * production -- sift3d_amd_rccl_transport below -- or anything a test provides):
+ *
+ *   halo      nearest-neighbour exchange of z planes: the input of every z FIR pass
+ *             (ceil(hw * unit_factor) + 1 planes per side), and after the pyramid the planes the
+ *             orientation / descriptor windows of this rank's keypoints reach into;
+ *   max       all-reduce(max) of max|input| (im_scale, imutil.c:699-713) and of the per-level
+ *             max|DoG| (sift.c:821-826) -- order-free, hence exact;
+ *   gather    all-gather of the per-level candidate counts, the candidates' |DoG| values and the
+ *             ORIENTED keypoints (rejected candidates never leave their rank).
+ *
+ * Ranks are concatenated in slab order inside each (octave, level), which reproduces the
+ * reference's global (o, s, z, y, x) order and its stale-strength quirk (sift.c:372-384), so the
+ * result equals the single-GPU result bit for bit (tests/test_gpu_sharded.py).  Mirror rules
+ * apply at the GLOBAL faces only: the stage kernels take the global length and the slab offset.
+ * Octaves whose slabs would be thinner than the window halo are all-gathered and computed on
+ * every rank (< 1 % of the voxels); their window work is still split by z.
+ *
+ * The z-halo exchange of a blur overlaps with the z pass of the slab's interior planes: the
+ * exchange is enqueued on a second stream as soon as the x pass has finished, the interior planes
+ * (which need no halo) are filtered meanwhile, the 2 * reach boundary planes afterwards.
+ *
+ * Scope: the default configuration of the detector (three keypoint levels per octave, 8-neighbour
+ * extrema, rows of whole quads); sift3d_amd_sharded_create refuses anything else.
+ * sift3d_amd/sharded.py is the same orchestration in Python (any configuration; it also runs on
+ * the CPU oracle backend in the gloo tests). */
+
+#include <dlfcn.h>
+
+#define SH_NGL 6
+#define SH_NDL 5
+#define SH_K 3
+#define SH_MAX_OCT 32
+#define SH_MAX_WORLD 64
+
+typedef struct {
+    float *t;           /* device planes [off, off + nloc) of the level */
+    int off, nloc;      /* local buffer */
+    int z0, z1;         /* owned (or, on replicated octaves, work-split) planes, global */
+    int nz_glob;
+} sh_level;
+
+typedef struct {          /* an oriented keypoint as exchanged between ranks */
+    int32_t o, s, x, y, z;
+    float R[9];
+} sh_gkp;
+
+struct sift3d_amd_sharded {
+    sift3d_amd_transport T;
+    int rank, world;
+    double peak_thresh, corner_thresh, sigma_n, sigma0;
+    double units[3];
+    int nx, ny, nz;
+    /* geometry */
+    int num_octaves, o_shard, halo;
+    int dims[SH_MAX_OCT][3];
+    int b0[SH_MAX_WORLD + 1];
+    int bounds[SH_MAX_OCT][SH_MAX_WORLD + 1];
+    int win_reach[SH_NGL];
+    filter_t filt[SH_NGL];
+    /* device state */
+    void *stream, *comm_stream, *ev_x, *ev_halo, *ev0, *ev1;
+    sh_level G[SH_MAX_OCT][SH_NGL];
+    sh_level tmp_a, tmp_b, im;       /* scratch levels of octave 0 size (re-described per octave) */
+    float *d_tmp_a, *d_tmp_b, *d_im, *d_raw, *d_stage;
+    size_t tmp_elems, stage_elems;
+    int in_z0, in_z1;
+    float *d_scalars;                /* [0] input max, [1] candidate count, [8 + 5 o + k] dogmax */
+    sift3d_hip_level h_levels[SH_MAX_OCT * SH_NGL], *d_levels;
+    void *d_work;
+    size_t work_bytes;
+    sift3d_hip_cand *d_cand, *h_cand;
+    float *d_R, *h_R;
+    int32_t *d_keep, *h_keep;
+    uint32_t cand_cap;
+    void *d_xchg, *h_xchg;           /* all-gather staging (device + pinned host mirror) */
+    size_t xchg_bytes;
+    sift3d_hip_kp *d_kp, *h_kp;
+    uint32_t kp_cap;
+    int ncand;
+    double t[4];                     /* pyramid device seconds, detect wall, describe wall, - */
+};
+
+static int sh_sharded(const sift3d_amd_sharded *S, int o) { return o < S->o_shard; }
+
+static double sh_scale(const sift3d_amd_sharded *S, int o, int s)
+{
+    return S->sigma0 * pow(2.0, o + (double)s / SH_K);           /* imutil.c:1578-1579 */
+}
+
+static size_t sh_plane(const sift3d_amd_sharded *S, int o) { return (size_t)S->dims[o][0] * S->dims[o][1]; }
+
+/* ---- geometry (sharded.py: Geometry) ------------------------------------------------------ */
+static int sh_geometry(sift3d_amd_sharded *S)
+{
+    int mn = S->nx < S->ny ? S->nx : S->ny, last, o, r, d[3], align, min_slab;
+    mn = mn < S->nz ? mn : S->nz;
+    last = (int)log2((double)mn) - 3;                              /* sift.c:442-444 */
+    if (last < 0) {
+        ERR("resize_SIFT3D: input image is too small: must have at least 8 voxels in each "
+            "dimension \n");
+        return SIFT3D_FAILURE;
+    }
+    S->num_octaves = last + 1;
+    if (S->num_octaves > SH_MAX_OCT)
+        return SIFT3D_FAILURE;
+    d[0] = S->nx; d[1] = S->ny; d[2] = S->nz;
+    for (o = 0; o < S->num_octaves; o++) {
+        memcpy(S->dims[o], d, sizeof(d));
+        d[0] /= 2; d[1] /= 2; d[2] /= 2;                           /* imutil.c:1545-1547 */
+    }
+    min_slab = S->halo + 8;
+    S->o_shard = 0;
+    if (S->world > 1)
+        while (S->o_shard < S->num_octaves && S->dims[S->o_shard][2] / S->world >= min_slab)
+            S->o_shard++;
+    /* slab bounds at octave 0: multiples of 2^o_shard, so that every slab boundary is even in
+     * every sharded octave and im_downsample_2x never needs a neighbour's plane */
+    align = 1 << S->o_shard;
+    S->b0[0] = 0;
+    for (r = 1; r < S->world; r++)
+        S->b0[r] = (int)nearbyint((double)S->nz * r / S->world / align) * align;
+    S->b0[S->world] = S->nz;
+    for (o = 0; o < S->num_octaves; o++) {
+        const int nzo = S->dims[o][2];
+        for (r = 0; r < S->world; r++)
+            S->bounds[o][r] = sh_sharded(S, o) ? ((S->b0[r] >> o) < nzo ? (S->b0[r] >> o) : nzo)
+                                                 : (int)((long)nzo * r / S->world);
+        S->bounds[o][S->world] = nzo;
+    }
+    return SIFT3D_SUCCESS;
+}
+
+static void sh_free_level(sh_level *L)
+{
+    sift3d_hip_free(L->t);
+    L->t = NULL;
+}
+
+void sift3d_amd_sharded_free(sift3d_amd_sharded *S)
+{
+    int o, s;
+    if (!S)
+        return;
+    if (S->stream)
+        sift3d_hip_stream_sync(S->stream);
+    if (S->comm_stream)
+        sift3d_hip_stream_sync(S->comm_stream);
+    for (o = 0; o < SH_MAX_OCT; o++)
+        for (s = 0; s < SH_NGL; s++)
+            sh_free_level(&S->G[o][s]);
+    for (s = 0; s < SH_NGL; s++)
+        free(S->filt[s].taps);
+    sift3d_hip_free(S->d_tmp_a); sift3d_hip_free(S->d_tmp_b); sift3d_hip_free(S->d_im);
+    sift3d_hip_free(S->d_raw); sift3d_hip_free(S->d_stage); sift3d_hip_free(S->d_scalars);
+    sift3d_hip_free(S->d_levels); sift3d_hip_free(S->d_work); sift3d_hip_free(S->d_cand);
+    sift3d_hip_free(S->d_R); sift3d_hip_free(S->d_keep); sift3d_hip_free(S->d_xchg);
+    sift3d_hip_free(S->d_kp);
+    sift3d_hip_host_free(S->h_cand); sift3d_hip_host_free(S->h_R); sift3d_hip_host_free(S->h_keep);
+    sift3d_hip_host_free(S->h_xchg); sift3d_hip_host_free(S->h_kp);
+    sift3d_hip_event_destroy(S->ev_x); sift3d_hip_event_destroy(S->ev_halo);
+    sift3d_hip_event_destroy(S->ev0); sift3d_hip_event_destroy(S->ev1);
+    sift3d_hip_stream_destroy(S->comm_stream);
+    sift3d_hip_stream_destroy(S->stream);
+    free(S);
+}
+
+sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift3d_amd_transport *T,
+                                              const sift3d_detector *params, double ux, double uy,
+                                              double uz)
+{
+    sift3d_amd_sharded *S;
+    int o, s, i, hw_max = 0, blur_reach;
+    size_t work = 0, n0;
+    if (!T || T->world < 1 || T->world > SH_MAX_WORLD || T->rank < 0 || T->rank >= T->world ||
+        nx < 8 || ny < 8 || nz < 8 || !(ux > 0) || !(uy > 0) || !(uz > 0))
+        return NULL;
+    if (T->world > 1 && (!T->halo || !T->allreduce_max || !T->allgather))
+        return NULL;
+    if (!sift3d_amd_device_available()) {
+        ERR("sift3d_amd: no HIP device is available; this library has no CPU path \n");
+        return NULL;
+    }
+    if (params && (params->num_kp_levels != SH_K || params->cuboid_extrema)) {
+        ERR("sift3d_amd_sharded: only the default configuration (3 keypoint levels per octave, "
+            "8-neighbour extrema) is supported by the C slab driver \n");
+        return NULL;
+    }
+    if (nx & 3) {
+        ERR("sift3d_amd_sharded: rows must be whole quads (nx %% 4 == 0) \n");
+        return NULL;
+    }
+    S = (sift3d_amd_sharded *)calloc(1, sizeof(*S));
+    if (!S)
+        return NULL;
+    S->T = *T;
+    S->rank = T->rank; S->world = T->world;
+    S->peak_thresh = params ? params->peak_thresh : peak_thresh_default;
+    S->corner_thresh = params ? params->corner_thresh : corner_thresh_default;
+    S->sigma_n = params ? params->sigma_n : sigma_n_default;
+    S->sigma0 = params ? params->sigma0 : sigma0_default;
+    S->units[0] = ux; S->units[1] = uy; S->units[2] = uz;
+    S->nx = nx; S->ny = ny; S->nz = nz;
+    if (S->sigma0 * pow(2.0, -1.0 / SH_K) < S->sigma_n) {          /* imutil.c:1582-1588 */
+        ERR("set_scales_Pyramid: sigma_n too large for these settings. \n");
+        goto fail;
+    }
+    /* filter bank (make_gss, imutil.c:1360-1409) */
+    for (i = 0; i < SH_NGL; i++) {
+        const double s_cur = i == 0 ? S->sigma_n : S->sigma0 * pow(2.0, (double)(i - 2) / SH_K);
+        const double s_next = S->sigma0 * pow(2.0, (double)(i - 1) / SH_K);
+        if (gauss_filter(&S->filt[i], sqrt(s_next * s_next - s_cur * s_cur)) ||
+            S->filt[i].width > SIFT3D_HIP_MAX_TAPS)
+            goto fail;
+        if (S->filt[i].width / 2 > hw_max)
+            hw_max = S->filt[i].width / 2;
+    }
+    /* halo planes a slab needs from its neighbours, in LEVEL planes (the same in every octave):
+     * descriptor window of Gaussian level s: 14.1422 * sigma0 * 2^((s-1)/K) / uz + 2
+     * (sift.c:1453-1454); z pass: ceil(hw * unit_factor) + 1 (imutil.c:756-757) */
+    for (s = 0; s < SH_NGL; s++)
+        S->win_reach[s] = (s >= 1 && s <= SH_K)
+                              ? (int)ceil(14.1422 * S->sigma0 * pow(2.0, (double)(s - 1) / SH_K) / uz) + 2
+                              : 1;
+    blur_reach = (int)ceil((double)hw_max * (double)(float)(1.0 / uz)) + 1;
+    S->halo = blur_reach;
+    for (s = 0; s < SH_NGL; s++)
+        if (S->win_reach[s] > S->halo)
+            S->halo = S->win_reach[s];
+    if (S->halo > 500) {
+        ERR("sift3d_amd_sharded: sigma0 / units give a %d-plane window \n", S->halo);
+        goto fail;
+    }
+    if (sh_geometry(S))
+        goto fail;
+    for (o = 0; o < S->num_octaves; o++)
+        if (S->dims[o][0] & 3) {
+            ERR("sift3d_amd_sharded: rows of octave %d are not whole quads (nx = %d) \n", o, S->dims[o][0]);
+            goto fail;
+        }
+    if (!(S->stream = sift3d_hip_stream_create()) || !(S->comm_stream = sift3d_hip_stream_create()) ||
+        !(S->ev_x = sift3d_hip_event_create()) || !(S->ev_halo = sift3d_hip_event_create()) ||
+        !(S->ev0 = sift3d_hip_event_create()) || !(S->ev1 = sift3d_hip_event_create()) || upload_mesh())
+        goto fail;
+    /* levels */
+    for (o = 0; o < S->num_octaves; o++) {
+        const int nzo = S->dims[o][2];
+        const int z0 = S->bounds[o][S->rank], z1 = S->bounds[o][S->rank + 1];
+        const int off = sh_sharded(S, o) ? (z0 - S->halo > 0 ? z0 - S->halo : 0) : 0;
+        const int hi = sh_sharded(S, o) ? (z1 + S->halo < nzo ? z1 + S->halo : nzo) : nzo;
+        const size_t w = sift3d_hip_extrema_work_bytes(S->dims[o][0], S->dims[o][1], hi - off, SH_K);
+        work = w > work ? w : work;
+        for (s = 0; s < SH_NGL; s++) {
+            sh_level *L = &S->G[o][s];
+            L->off = off; L->nloc = hi - off; L->z0 = z0; L->z1 = z1; L->nz_glob = nzo;
+            if (!(L->t = (float *)sift3d_hip_malloc(sh_plane(S, o) * (size_t)L->nloc * sizeof(float))))
+                goto fail;
+        }
+    }
+    n0 = sh_plane(S, 0) * (size_t)S->G[0][0].nloc;
+    S->tmp_elems = n0;
+    S->in_z0 = sh_sharded(S, 0) ? S->bounds[0][S->rank] : 0;
+    S->in_z1 = sh_sharded(S, 0) ? S->bounds[0][S->rank + 1] : nz;
+    S->d_tmp_a = (float *)sift3d_hip_malloc(n0 * sizeof(float));
+    S->d_tmp_b = (float *)sift3d_hip_malloc(n0 * sizeof(float));
+    S->d_im = (float *)sift3d_hip_malloc(n0 * sizeof(float));
+    S->d_raw = (float *)sift3d_hip_malloc(sh_plane(S, 0) * (size_t)(S->in_z1 - S->in_z0) * sizeof(float));
+    /* staging of the sharded -> replicated transition: this rank's down-sampled slab, then the
+     * world slabs gathered (all padded to the largest) */
+    {
+        size_t stage = 16;
+        if (S->world > 1 && S->o_shard >= 1 && S->o_shard < S->num_octaves) {
+            const int t = S->o_shard, mzg = S->dims[t][2];
+            int r, mxn = 1;
+            for (r = 0; r < S->world; r++) {
+                int lo = S->b0[r] >> t, hi = r + 1 < S->world ? S->b0[r + 1] >> t : mzg;
+                lo = lo < mzg ? lo : mzg;
+                hi = hi < mzg ? hi : mzg;
+                if (hi - lo > mxn)
+                    mxn = hi - lo;
+            }
+            stage = (size_t)mxn * sh_plane(S, t) * (size_t)(S->world + 1);
+        }
+        S->stage_elems = stage;
+        S->d_stage = (float *)sift3d_hip_malloc(stage * sizeof(float));
+    }
+    S->d_scalars = (float *)sift3d_hip_malloc(sizeof(float) * (8 + SH_NDL * SH_MAX_OCT));
+    S->d_levels = (sift3d_hip_level *)sift3d_hip_malloc(sizeof(sift3d_hip_level) * SH_MAX_OCT * SH_NGL);
+    S->d_work = sift3d_hip_malloc(work);
+    S->work_bytes = work;
+    if (!S->d_tmp_a || !S->d_tmp_b || !S->d_im || !S->d_raw || !S->d_stage || !S->d_scalars ||
+        !S->d_levels || !S->d_work)
+        goto fail;
+    /* level table (window kernels) */
+    for (o = 0; o < S->num_octaves; o++)
+        for (s = 0; s < SH_NGL; s++) {
+            sift3d_hip_level *L = &S->h_levels[o * SH_NGL + s];
+            L->data = S->G[o][s].t;
+            L->nx = S->dims[o][0]; L->ny = S->dims[o][1]; L->nz = S->G[o][s].nloc;
+            L->z_off = S->G[o][s].off;
+            L->nz_glob = S->dims[o][2];
+            L->ux = (float)(ux * ldexp(1.0, o));
+            L->uy = (float)(uy * ldexp(1.0, o));
+            L->uz = (float)(uz * ldexp(1.0, o));
+            L->octave = o;
+            L->sd = sh_scale(S, o, s - 1);
+        }
+    if (sift3d_hip_memcpy_h2d(S->d_levels, S->h_levels,
+                              sizeof(sift3d_hip_level) * (size_t)S->num_octaves * SH_NGL, S->stream) ||
+        sift3d_hip_stream_sync(S->stream))
+        goto fail;
+    return S;
+fail:
+    sift3d_amd_sharded_free(S);
+    return NULL;
+}
+
+int sift3d_amd_sharded_own_planes(const sift3d_amd_sharded *S, int *z0, int *z1)
+{
+    if (!S)
+        return SIFT3D_FAILURE;
+    if (z0) *z0 = S->in_z0;
+    if (z1) *z1 = S->in_z1;
+    return SIFT3D_SUCCESS;
+}
+
+float *sift3d_amd_sharded_input(sift3d_amd_sharded *S) { return S ? S->d_raw : NULL; }
+
+int sift3d_amd_sharded_synth(sift3d_amd_sharded *S, uint64_t seed)
+{
+    if (!S)
+        return SIFT3D_FAILURE;
+    if (sift3d_hip_synth_lattice(S->d_raw, S->nx, S->ny, S->in_z1 - S->in_z0, S->in_z0, seed, S->stream))
+        return SIFT3D_FAILURE;
+    return sift3d_hip_stream_sync(S->stream);
+}
+
+int sift3d_amd_sharded_num_candidates(const sift3d_amd_sharded *S) { return S ? S->ncand : -1; }
+const double *sift3d_amd_sharded_timings(const sift3d_amd_sharded *S) { return S->t; }
+int sift3d_amd_sharded_info(const sift3d_amd_sharded *S, int *num_octaves, int *o_shard, int *halo)
+{
+    if (!S)
+        return SIFT3D_FAILURE;
+    if (num_octaves) *num_octaves = S->num_octaves;
+    if (o_shard) *o_shard = S->o_shard;
+    if (halo) *halo = S->halo;
+    return SIFT3D_SUCCESS;
+}
+
+/* ---- exchanges ------------------------------------------------------------------------------ */
+/* Fill the h halo planes on both sides of the owned range of a level buffer (plane stride
+ * `plane`, geometry of `L`) from the slab neighbours, on `stream`. */
+static int sh_halo(sift3d_amd_sharded *S, float *t, const sh_level *L, size_t plane, int h, void *stream)
+{
+    const int a = L->z0 - L->off, b = L->z1 - L->off;
+    const int lo = S->rank > 0 && L->z0 > 0, hi = S->rank < S->world - 1 && L->z1 < L->nz_glob;
+    if (S->world == 1 || h <= 0 || (!lo && !hi))
+        return SIFT3D_SUCCESS;
+    if (h > S->halo || h > b - a) {
+        ERR("sift3d_amd_sharded: a %d-plane halo does not fit slabs of %d planes \n", h, b - a);
+        return SIFT3D_FAILURE;
+    }
+    return S->T.halo(S->T.ctx, lo ? t + (size_t)a * plane : NULL, lo ? t + (size_t)(a - h) * plane : NULL,
+                     hi ? t + (size_t)(b - h) * plane : NULL, hi ? t + (size_t)b * plane : NULL,
+                     (size_t)h * plane * sizeof(float), stream);
+}
+
+static int sh_fir(sift3d_amd_sharded *S, const float *src, float *dst, int o, int nloc, int axis,
+                  const filter_t *f, float uf, int off, int z_lo, int z_hi, void *stream)
+{
+    sift3d_hip_fir_args a;
+    memset(&a, 0, sizeof(a));
+    a.src = src; a.dst = dst;
+    a.nx = S->dims[o][0]; a.ny = S->dims[o][1]; a.nz = nloc;
+    a.axis = axis; a.width = f->width; a.taps = f->taps;
+    a.unit_factor = uf;
+    a.n_glob = S->dims[o][2]; a.off = off;
+    a.z_lo = z_lo; a.z_hi = z_hi;
+    return sift3d_hip_fir(&a, stream);
+}
+
+/* apply_Sep_FIR_filter (imutil.c:1127-1206) on a level: src -> dst (same geometry).  Sharded
+ * octaves: x (and y) on the owned planes, halo exchange of the z pass's input overlapped with the
+ * z pass of the interior planes. */
+static int sh_blur(sift3d_amd_sharded *S, int o, const float *src, const sh_level *Lg, float *dst,
+                   const filter_t *f)
+{
+    const size_t plane = sh_plane(S, o);
+    const int nx = S->dims[o][0], ny = S->dims[o][1], nzo = S->dims[o][2];
+    const float ufx = (float)(1.0 / (S->units[0] * ldexp(1.0, o)));
+    const float ufy = (float)(1.0 / (S->units[1] * ldexp(1.0, o)));
+    const float ufz = (float)(1.0 / (S->units[2] * ldexp(1.0, o)));
+    const int hw = f->width / 2;
+    const int a = sh_sharded(S, o) ? Lg->z0 - Lg->off : 0;
+    const int b = sh_sharded(S, o) ? Lg->z1 - Lg->off : Lg->nloc;
+    const int reach = (int)ceilf((float)hw * ufz) + 1;
+    const int exch = S->world > 1 && sh_sharded(S, o);
+    float *zin;
+    int fused, ia, ib, rc;
+    if (sh_fir(S, src, S->d_tmp_a, o, Lg->nloc, 0, f, ufx, 0, a, b, S->stream))
+        return SIFT3D_FAILURE;
+    fused = ufy == 1.0f && ufz == 1.0f && hw >= 1 && hw <= 8 && ny >= 2 * hw + 2 && nzo >= 2 * hw + 2;
+    zin = S->d_tmp_a;
+    if (!fused) {
+        if (sh_fir(S, S->d_tmp_a, S->d_tmp_b, o, Lg->nloc, 1, f, ufy, 0, a, b, S->stream))
+            return SIFT3D_FAILURE;
+        zin = S->d_tmp_b;
+    }
+    /* interior planes need no halo: [ia, ib) */
+    ia = exch && Lg->z0 > 0 ? a + reach : a;
+    ib = exch && Lg->z1 < nzo ? b - reach : b;
+    if (ib < ia)
+        ia = ib = a;                                     /* thin slab: everything after the exchange */
+    if (exch) {
+        if (sift3d_hip_event_record(S->ev_x, S->stream) ||
+            sift3d_hip_stream_wait_event(S->comm_stream, S->ev_x) ||
+            sh_halo(S, zin, Lg, plane, reach, S->comm_stream) ||
+            sift3d_hip_event_record(S->ev_halo, S->comm_stream))
+            return SIFT3D_FAILURE;
+    }
+#define SH_ZPASS(lo_, hi_)                                                                           \
+    do {                                                                                             \
+        if ((hi_) > (lo_)) {                                                                         \
+            if (fused) {                                                                             \
+                rc = sift3d_hip_fir_yz_u1(zin, dst, nx, ny, Lg->nloc, f->taps, f->width, nzo,        \
+                                          Lg->off, (lo_), (hi_), S->stream);                         \
+                if (rc != SIFT3D_SUCCESS)                                                            \
+                    return SIFT3D_FAILURE;                                                           \
+            } else if (sh_fir(S, zin, dst, o, Lg->nloc, 2, f, ufz, Lg->off, (lo_), (hi_), S->stream)) \
+                return SIFT3D_FAILURE;                                                               \
+        }                                                                                            \
+    } while (0)
+    SH_ZPASS(ia, ib);
+    if (exch) {
+        if (sift3d_hip_stream_wait_event(S->stream, S->ev_halo))
+            return SIFT3D_FAILURE;
+        SH_ZPASS(a, ia);
+        SH_ZPASS(ib, b);
+    }
+#undef SH_ZPASS
+    return SIFT3D_SUCCESS;
+}
+
+/* all-gather of `bytes` host bytes per rank through the device staging buffer; result (world *
+ * bytes, rank order) in S->h_xchg */
+static int sh_allgather_host(sift3d_amd_sharded *S, const void *mine, size_t bytes)
+{
+    const size_t pad = (bytes + 15) & ~(size_t)15;
+    const size_t need = pad * (size_t)(S->world + 1);
+    if (need > S->xchg_bytes) {
+        sift3d_hip_free(S->d_xchg);
+        sift3d_hip_host_free(S->h_xchg);
+        S->xchg_bytes = 0;
+        S->d_xchg = sift3d_hip_malloc(need + need / 4);
+        S->h_xchg = sift3d_hip_host_alloc(need + need / 4);
+        if (!S->d_xchg || !S->h_xchg)
+            return SIFT3D_FAILURE;
+        S->xchg_bytes = need + need / 4;
+    }
+    if (S->world == 1) {
+        memcpy(S->h_xchg, mine, bytes);
+        return SIFT3D_SUCCESS;
+    }
+    /* layout: [world * pad] gathered, then [pad] my contribution */
+    memset((char *)S->h_xchg + pad * S->world, 0, pad);
+    memcpy((char *)S->h_xchg + pad * S->world, mine, bytes);
+    if (sift3d_hip_memcpy_h2d((char *)S->d_xchg + pad * S->world, (char *)S->h_xchg + pad * S->world, pad,
+                              S->stream) ||
+        S->T.allgather(S->T.ctx, (char *)S->d_xchg + pad * S->world, S->d_xchg, pad, S->stream) ||
+        sift3d_hip_memcpy_d2h(S->h_xchg, S->d_xchg, pad * S->world, S->stream) ||
+        sift3d_hip_stream_sync(S->stream))
+        return SIFT3D_FAILURE;
+    return SIFT3D_SUCCESS;
+}
+
+static int sh_ensure_cand(sift3d_amd_sharded *S, uint32_t cap)
+{
+    if (cap <= S->cand_cap)
+        return SIFT3D_SUCCESS;
+    sift3d_hip_free(S->d_cand); sift3d_hip_free(S->d_R); sift3d_hip_free(S->d_keep);
+    sift3d_hip_host_free(S->h_cand); sift3d_hip_host_free(S->h_R); sift3d_hip_host_free(S->h_keep);
+    S->cand_cap = 0;
+    S->d_cand = (sift3d_hip_cand *)sift3d_hip_malloc(sizeof(sift3d_hip_cand) * (size_t)cap);
+    S->d_R = (float *)sift3d_hip_malloc(sizeof(float) * 9 * (size_t)cap);
+    S->d_keep = (int32_t *)sift3d_hip_malloc(sizeof(int32_t) * (size_t)cap);
+    S->h_cand = (sift3d_hip_cand *)sift3d_hip_host_alloc(sizeof(sift3d_hip_cand) * (size_t)cap);
+    S->h_R = (float *)sift3d_hip_host_alloc(sizeof(float) * 9 * (size_t)cap);
+    S->h_keep = (int32_t *)sift3d_hip_host_alloc(sizeof(int32_t) * (size_t)cap);
+    if (!S->d_cand || !S->d_R || !S->d_keep || !S->h_cand || !S->h_R || !S->h_keep)
+        return SIFT3D_FAILURE;
+    S->cand_cap = cap;
+    return SIFT3D_SUCCESS;
+}
+
+/* ---- detect -------------------------------------------------------------------------------- */
+int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
+{
+    const double t_start = now_s();
+    const int nkey = S->num_octaves * SH_K;
+    uint32_t count = 0;
+    int o, s, r, i, k, attempt;
+    if (!S || !kp)
+        return SIFT3D_FAILURE;
+
+    /* set_im_SIFT3D: scale by the GLOBAL max|v| (sift.c:645-649) */
+    {
+        const size_t n_in = sh_plane(S, 0) * (size_t)(S->in_z1 - S->in_z0);
+        const sh_level *L0 = &S->G[0][0];
+        const int a = sh_sharded(S, 0) ? L0->z0 - L0->off : 0;
+        if (sift3d_hip_memset(S->d_scalars, 0, sizeof(float) * (8 + SH_NDL * SH_MAX_OCT), S->stream) ||
+            sift3d_hip_absmax(S->d_raw, n_in, S->d_scalars, S->stream))
+            return SIFT3D_FAILURE;
+        if (S->world > 1 && S->T.allreduce_max(S->T.ctx, S->d_scalars, 1, S->stream))
+            return SIFT3D_FAILURE;
+        if (sift3d_hip_scale(S->d_raw, S->d_im + (size_t)a * sh_plane(S, 0), n_in, S->d_scalars, S->stream))
+            return SIFT3D_FAILURE;
+    }
+    /* build_gpyr, sift.c:662-711 */
+    sift3d_hip_event_record(S->ev0, S->stream);
+    for (o = 0; o < S->num_octaves; o++) {
+        if (o == 0 && sh_blur(S, 0, S->d_im, &S->G[0][0], S->G[0][0].t, &S->filt[0]))
+            return SIFT3D_FAILURE;
+        for (s = 1; s < SH_NGL; s++)
+            if (sh_blur(S, o, S->G[o][s - 1].t, &S->G[o][s], S->G[o][s].t, &S->filt[s]))
+                return SIFT3D_FAILURE;
+        if (o != S->num_octaves - 1) {
+            /* level max(s_end - 2, first_level) = Gaussian index 3, sift.c:696-704 */
+            const sh_level *src = &S->G[o][3];
+            sh_level *dst = &S->G[o + 1][0];
+            const int mx = S->dims[o + 1][0], my = S->dims[o + 1][1], mzg = S->dims[o + 1][2];
+            const size_t pl_s = sh_plane(S, o), pl_d = sh_plane(S, o + 1);
+            if (sh_sharded(S, o) && !sh_sharded(S, o + 1)) {
+                /* transition to the replicated octaves: down-sample the owned planes into a
+                 * staging slab, all-gather the slabs (padded to the largest) */
+                int zb[SH_MAX_WORLD + 1], mxn = 1;
+                for (r = 0; r < S->world; r++) {
+                    zb[r] = S->b0[r] >> (o + 1);
+                    if (zb[r] > mzg) zb[r] = mzg;
+                }
+                zb[S->world] = mzg;
+                for (r = 0; r < S->world; r++)
+                    if (zb[r + 1] - zb[r] > mxn) mxn = zb[r + 1] - zb[r];
+                {
+                    const int z0 = zb[S->rank], z1 = zb[S->rank + 1];
+                    float *mine = S->d_stage, *all;
+                    const size_t slab = (size_t)mxn * pl_d;
+                    if (slab * (size_t)(S->world + 1) > S->stage_elems)
+                        return SIFT3D_FAILURE;
+                    all = mine + slab;
+                    if (sift3d_hip_memset(mine, 0, slab * sizeof(float), S->stream))
+                        return SIFT3D_FAILURE;
+                    if (z1 > z0 && sift3d_hip_downsample2(src->t + (size_t)(2 * z0 - src->off) * pl_s,
+                                                          S->dims[o][0], S->dims[o][1], mine, mx, my,
+                                                          z1 - z0, S->stream))
+                        return SIFT3D_FAILURE;
+                    if (S->T.allgather(S->T.ctx, mine, all, slab * sizeof(float), S->stream))
+                        return SIFT3D_FAILURE;
+                    for (r = 0; r < S->world; r++)
+                        if (zb[r + 1] > zb[r] &&
+                            sift3d_hip_memcpy_d2d(dst->t + (size_t)zb[r] * pl_d, all + (size_t)r * slab,
+                                                  (size_t)(zb[r + 1] - zb[r]) * pl_d * sizeof(float),
+                                                  S->stream))
+                            return SIFT3D_FAILURE;
+                }
+            } else {
+                const int z0 = sh_sharded(S, o + 1) ? dst->z0 : 0, z1 = sh_sharded(S, o + 1) ? dst->z1 : mzg;
+                if (z1 > z0 && sift3d_hip_downsample2(src->t + (size_t)(2 * z0 - src->off) * pl_s,
+                                                      S->dims[o][0], S->dims[o][1],
+                                                      dst->t + (size_t)(z0 - dst->off) * pl_d, mx, my,
+                                                      z1 - z0, S->stream))
+                    return SIFT3D_FAILURE;
+            }
+        }
+    }
+    sift3d_hip_event_record(S->ev1, S->stream);
+
+    /* window / DoG halos of the sharded octaves */
+    for (o = 0; o < S->o_shard; o++)
+        for (s = 0; s < SH_NGL; s++)
+            if (sh_halo(S, S->G[o][s].t, &S->G[o][s], sh_plane(S, o), S->win_reach[s], S->stream))
+                return SIFT3D_FAILURE;
+
+    /* dogmax (sift.c:821-826) of every octave on the owned planes (+ 1: harmless for a max), one
+     * all-reduce for all of them; no DoG level is stored */
+    for (o = 0; o < S->num_octaves; o++) {
+        const sh_level *L = &S->G[o][0];
+        const int a = L->z0 - L->off, b = L->z1 - L->off;
+        const int lo = sh_sharded(S, o) ? (a - 1 > 0 ? a - 1 : 0) : 0;
+        const int hi = sh_sharded(S, o) ? (b + 1 < L->nloc ? b + 1 : L->nloc) : L->nloc;
+        const float *g[SH_NGL];
+        for (s = 0; s < SH_NGL; s++)
+            g[s] = S->G[o][s].t + (size_t)lo * sh_plane(S, o);
+        if (hi > lo && sift3d_hip_dogmax_stack(g, SH_NGL, (size_t)(hi - lo) * sh_plane(S, o),
+                                               S->d_scalars + 8 + SH_NDL * o, S->stream) != SIFT3D_SUCCESS)
+            return SIFT3D_FAILURE;
+    }
+    if (S->world > 1 &&
+        S->T.allreduce_max(S->T.ctx, S->d_scalars + 8, SH_NDL * S->num_octaves, S->stream))
+        return SIFT3D_FAILURE;
+
+    /* detect_extrema (sift.c:735-871) on the owned planes, assign_orientations (sift.c:1109-1167)
+     * for the local candidates */
+    if (sh_ensure_cand(S, S->cand_cap ? S->cand_cap : (1u << 18)))
+        return SIFT3D_FAILURE;
+    for (attempt = 0; attempt < 2; attempt++) {
+        if (sift3d_hip_memset(S->d_scalars + 1, 0, sizeof(uint32_t), S->stream))
+            return SIFT3D_FAILURE;
+        for (o = 0; o < S->num_octaves; o++) {
+            const sh_level *L = &S->G[o][0];
+            const int nzo = S->dims[o][2];
+            const int zl = (L->z0 > 1 ? L->z0 : 1) - L->off;
+            int zh = (L->z1 < nzo - 1 ? L->z1 : nzo - 1) - L->off;
+            const float *g[SH_NGL];
+            if (zh < zl)
+                zh = zl;
+            for (s = 0; s < SH_NGL; s++)
+                g[s] = S->G[o][s].t;
+            if (L->nloc < 3 || zh <= zl)
+                continue;                                /* no interior plane on this rank */
+            if (sift3d_hip_extrema_gauss6(g, S->d_scalars + 8 + SH_NDL * o, S->dims[o][0], S->dims[o][1],
+                                          L->nloc, zl, zh, o * SH_NGL + 1, S->peak_thresh, S->d_cand,
+                                          S->cand_cap, (uint32_t *)(S->d_scalars + 1), S->d_work,
+                                          S->work_bytes, S->stream) != SIFT3D_SUCCESS)
+                return SIFT3D_FAILURE;
+        }
+        if (sift3d_hip_memcpy_d2h(&count, S->d_scalars + 1, sizeof(count), S->stream) ||
+            sift3d_hip_stream_sync(S->stream))
+            return SIFT3D_FAILURE;
+        if (count <= S->cand_cap)
+            break;
+        if (sh_ensure_cand(S, count + count / 4 + 1024))
+            return SIFT3D_FAILURE;
+    }
+    if (count) {
+        if (sift3d_hip_orient(S->d_levels, S->d_cand, count, S->corner_thresh, S->d_R, S->d_keep,
+                              S->stream) ||
+            sift3d_hip_memcpy_d2h(S->h_cand, S->d_cand, sizeof(sift3d_hip_cand) * (size_t)count, S->stream) ||
+            sift3d_hip_memcpy_d2h(S->h_R, S->d_R, sizeof(float) * 9 * (size_t)count, S->stream) ||
+            sift3d_hip_memcpy_d2h(S->h_keep, S->d_keep, sizeof(int32_t) * (size_t)count, S->stream))
+            return SIFT3D_FAILURE;
+    }
+    if (sift3d_hip_stream_sync(S->stream))
+        return SIFT3D_FAILURE;
+
+    /* Exchange (all-gather): per-(o,s) counts, the candidates' |DoG| values and the
+     * ORIENTED keypoints only.  Global order: (o, s) major, then ranks in slab order (their z
+     * ranges are disjoint and ascending), each rank's list already in (z, y, x) order. */
+    {
+        int32_t *cnt = (int32_t *)calloc((size_t)nkey * 2, sizeof(int32_t));
+        int32_t *allcnt;
+        int64_t *cc, *ck;            /* per rank prefix sums over keys: candidates / kept */
+        size_t nkept = 0, maxc = 0, maxk = 0, tot_c = 0, tot_k = 0, j;
+        float *vals;
+        sh_gkp *recs;
+        if (!cnt)
+            return SIFT3D_FAILURE;
+        for (i = 0; i < (int)count; i++) {
+            const int tag = S->h_cand[i].tag;
+            const int key = (tag / SH_NGL) * SH_K + (tag % SH_NGL - 1);
+            cnt[2 * key]++;
+            if (S->h_keep[i]) {
+                cnt[2 * key + 1]++;
+                nkept++;
+            }
+        }
+        if (sh_allgather_host(S, cnt, sizeof(int32_t) * 2 * (size_t)nkey)) {
+            free(cnt);
+            return SIFT3D_FAILURE;
+        }
+        free(cnt);
+        {
+            const size_t pad = (sizeof(int32_t) * 2 * (size_t)nkey + 15) & ~(size_t)15;
+            allcnt = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)nkey * S->world);
+            cc = (int64_t *)calloc((size_t)(nkey + 1) * S->world, sizeof(int64_t));
+            ck = (int64_t *)calloc((size_t)(nkey + 1) * S->world, sizeof(int64_t));
+            if (!allcnt || !cc || !ck) {
+                free(allcnt); free(cc); free(ck);
+                return SIFT3D_FAILURE;
+            }
+            for (r = 0; r < S->world; r++) {
+                memcpy(allcnt + (size_t)r * 2 * nkey, (char *)S->h_xchg + pad * (S->world == 1 ? 0 : r),
+                       sizeof(int32_t) * 2 * (size_t)nkey);
+                for (k = 0; k < nkey; k++) {
+                    cc[(size_t)r * (nkey + 1) + k + 1] = cc[(size_t)r * (nkey + 1) + k] + allcnt[((size_t)r * nkey + k) * 2];
+                    ck[(size_t)r * (nkey + 1) + k + 1] = ck[(size_t)r * (nkey + 1) + k] + allcnt[((size_t)r * nkey + k) * 2 + 1];
+                }
+                if ((size_t)cc[(size_t)r * (nkey + 1) + nkey] > maxc) maxc = (size_t)cc[(size_t)r * (nkey + 1) + nkey];
+                if ((size_t)ck[(size_t)r * (nkey + 1) + nkey] > maxk) maxk = (size_t)ck[(size_t)r * (nkey + 1) + nkey];
+                tot_c += (size_t)cc[(size_t)r * (nkey + 1) + nkey];
+                tot_k += (size_t)ck[(size_t)r * (nkey + 1) + nkey];
+            }
+        }
+        S->ncand = (int)tot_c;
+        /* kept records of this rank, global coordinates */
+        recs = (sh_gkp *)calloc(maxk ? maxk : 1, sizeof(sh_gkp));
+        vals = (float *)calloc(maxc ? maxc : 1, sizeof(float));
+        if (!recs || !vals) {
+            free(recs); free(vals); free(allcnt); free(cc); free(ck);
+            return SIFT3D_FAILURE;
+        }
+        for (i = 0, j = 0; i < (int)count; i++) {
+            const sift3d_hip_cand *c = S->h_cand + i;
+            const int oo = c->tag / SH_NGL;
+            const size_t plane = sh_plane(S, oo);
+            const uint32_t rem = (uint32_t)(c->idx % plane);
+            vals[i] = c->val;
+            if (!S->h_keep[i])
+                continue;
+            recs[j].o = oo;
+            recs[j].s = c->tag % SH_NGL - 1;
+            recs[j].x = (int32_t)(rem % (uint32_t)S->dims[oo][0]);
+            recs[j].y = (int32_t)(rem / (uint32_t)S->dims[oo][0]);
+            recs[j].z = (int32_t)(c->idx / plane) + S->G[oo][0].off;
+            memcpy(recs[j].R, S->h_R + 9 * (size_t)i, sizeof(recs[j].R));
+            j++;
+        }
+        /* keypoint store: dimensions of the first octave (sift.c:756-759) */
+        kp->nx = S->nx; kp->ny = S->ny; kp->nz = S->nz;
+        if (kp_store_resize(kp, tot_k)) {
+            free(recs); free(vals); free(allcnt); free(cc); free(ck);
+            return SIFT3D_FAILURE;
+        }
+        /* values first (the staging buffer is reused): copy_Keypoint omits `strength`
+         * (sift.c:372-384), so slot j keeps GLOBAL candidate j's value (quirk Q2): only the first
+         * tot_k values of the global candidate order matter */
+        if (sh_allgather_host(S, vals, sizeof(float) * (maxc ? maxc : 1))) {
+            free(recs); free(vals); free(allcnt); free(cc); free(ck);
+            return SIFT3D_FAILURE;
+        }
+        {
+            const size_t pad = (sizeof(float) * (maxc ? maxc : 1) + 15) & ~(size_t)15;
+            size_t got = 0;
+            for (k = 0; k < nkey && got < tot_k; k++)
+                for (r = 0; r < S->world && got < tot_k; r++) {
+                    const float *v = (const float *)((char *)S->h_xchg + pad * (S->world == 1 ? 0 : r));
+                    int64_t q;
+                    for (q = cc[(size_t)r * (nkey + 1) + k]; q < cc[(size_t)r * (nkey + 1) + k + 1] && got < tot_k; q++)
+                        kp->buf[got++].strength = v[q];
+                }
+        }
+        if (sh_allgather_host(S, recs, sizeof(sh_gkp) * (maxk ? maxk : 1))) {
+            free(recs); free(vals); free(allcnt); free(cc); free(ck);
+            return SIFT3D_FAILURE;
+        }
+        {
+            const size_t pad = (sizeof(sh_gkp) * (maxk ? maxk : 1) + 15) & ~(size_t)15;
+            size_t got = 0;
+            for (k = 0; k < nkey; k++)
+                for (r = 0; r < S->world; r++) {
+                    const sh_gkp *g = (const sh_gkp *)((char *)S->h_xchg + pad * (S->world == 1 ? 0 : r));
+                    int64_t q;
+                    for (q = ck[(size_t)r * (nkey + 1) + k]; q < ck[(size_t)r * (nkey + 1) + k + 1]; q++) {
+                        keypoint_t *kk = kp->buf + got++;
+                        kk->o = g[q].o; kk->s = g[q].s;
+                        kk->xd = g[q].x; kk->yd = g[q].y; kk->zd = g[q].z;
+                        kk->sd = sh_scale(S, g[q].o, g[q].s);
+                        memcpy(kk->R, g[q].R, sizeof(kk->R));
+                    }
+                }
+        }
+        free(recs); free(vals); free(allcnt); free(cc); free(ck);
+    }
+    S->t[0] = 1e-3 * sift3d_hip_event_elapsed_ms(S->ev0, S->ev1);
+    S->t[1] = now_s() - t_start;
+    return SIFT3D_SUCCESS;
+}
+
+/* ---- describe ------------------------------------------------------------------------------ */
+/* Descriptors of the keypoints this rank owns (by z).  own_idx (capacity: the number of
+ * keypoints) receives their positions in `kp`; desc their descriptors in that order.  The union
+ * over ranks covers every keypoint exactly once. */
+int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_store *kp,
+                                sift3d_descriptor_store *desc, int *own_idx, int *n_own)
+{
+    const double t_start = now_s();
+    const int num = (int)kp->num;
+    int i, n = 0, sv, pos = 0;
+    if (!S || !kp || !desc || !own_idx || !n_own)
+        return SIFT3D_FAILURE;
+    for (i = 0; i < num; i++) {
+        const keypoint_t *k = kp->buf + i;
+        if (k->o < 0 || k->o >= S->num_octaves || k->s < 0 || k->s >= SH_K)
+            return SIFT3D_FAILURE;
+        if (S->world == 1 || (k->zd >= (double)S->bounds[k->o][S->rank] &&
+                              k->zd < (double)S->bounds[k->o][S->rank + 1]))
+            own_idx[n++] = i;
+    }
+    *n_own = n;
+    desc->nx = S->nx; desc->ny = S->ny; desc->nz = S->nz;
+    if (!desc->pinned || (size_t)n > desc->cap) {
+        const size_t cap = (size_t)n + (size_t)n / 8 + 64;
+        desc_store_release(desc);
+        desc->hist = (float *)sift3d_hip_host_alloc(sizeof(float) * DESC_NUMEL * cap);
+        desc->xyzsd = (double *)malloc(sizeof(double) * 4 * cap);
+        if (!desc->hist || !desc->xyzsd) {
+            desc->pinned = desc->hist != NULL;
+            desc_store_release(desc);
+            return SIFT3D_FAILURE;
+        }
+        desc->pinned = 1;
+        desc->cap = cap;
+    }
+    desc->num = (size_t)n;
+    if (!n)
+        return SIFT3D_SUCCESS;
+    if ((uint32_t)n > S->kp_cap) {
+        const uint32_t cap = (uint32_t)n + (uint32_t)n / 4 + 256;
+        sift3d_hip_free(S->d_kp);
+        sift3d_hip_host_free(S->h_kp);
+        S->kp_cap = 0;
+        S->d_kp = (sift3d_hip_kp *)sift3d_hip_malloc(sizeof(sift3d_hip_kp) * (size_t)cap);
+        S->h_kp = (sift3d_hip_kp *)sift3d_hip_host_alloc(sizeof(sift3d_hip_kp) * (size_t)cap);
+        if (!S->d_kp || !S->h_kp)
+            return SIFT3D_FAILURE;
+        S->kp_cap = cap;
+    }
+    /* launch order: widest windows first, each histogram to its own row */
+    for (sv = SH_K - 1; sv >= 0; sv--)
+        for (i = 0; i < n; i++) {
+            const keypoint_t *k = kp->buf + own_idx[i];
+            sift3d_hip_kp *q;
+            if (k->s != sv)
+                continue;
+            q = S->h_kp + pos++;
+            memcpy(q->R, k->R, sizeof(q->R));
+            q->cx = (float)k->xd; q->cy = (float)k->yd; q->cz = (float)k->zd;   /* sift.c:1474-1476 */
+            q->level = k->o * SH_NGL + k->s + 1;
+            q->row1 = (uint32_t)i + 1u;
+            q->sd = k->sd;
+        }
+    for (i = 0; i < n; i++) {
+        const keypoint_t *k = kp->buf + own_idx[i];
+        const double f = ldexp(1.0, k->o);                 /* sift.c:1459, 1530-1533 */
+        desc->xyzsd[4 * (size_t)i] = k->xd * f;
+        desc->xyzsd[4 * (size_t)i + 1] = k->yd * f;
+        desc->xyzsd[4 * (size_t)i + 2] = k->zd * f;
+        desc->xyzsd[4 * (size_t)i + 3] = k->sd;
+    }
+    {
+        float *dev_view = (float *)sift3d_hip_host_device_ptr(desc->hist);
+        if (!dev_view ||
+            sift3d_hip_memcpy_h2d(S->d_kp, S->h_kp, sizeof(sift3d_hip_kp) * (size_t)n, S->stream) ||
+            sift3d_hip_describe(S->d_levels, S->d_kp, (uint32_t)n, dev_view, S->stream) ||
+            sift3d_hip_stream_sync(S->stream))
+            return SIFT3D_FAILURE;
+    }
+    S->t[2] = now_s() - t_start;
+    return SIFT3D_SUCCESS;
+}
+
+/* ---- RCCL transport (librccl is loaded at run time: single-GPU users do not need it) -------- */
+typedef struct { char internal[128]; } sh_nccl_id;
+typedef void *sh_nccl_comm;
+typedef struct {
+    void *lib;
+    sh_nccl_comm comm;
+    int rank, world;
+    int (*GetUniqueId)(sh_nccl_id *);
+    int (*CommInitRank)(sh_nccl_comm *, int, sh_nccl_id, int);
+    int (*CommDestroy)(sh_nccl_comm);
+    int (*Send)(const void *, size_t, int, int, sh_nccl_comm, void *);
+    int (*Recv)(void *, size_t, int, int, sh_nccl_comm, void *);
+    int (*AllReduce)(const void *, void *, size_t, int, int, sh_nccl_comm, void *);
+    int (*AllGather)(const void *, void *, size_t, int, sh_nccl_comm, void *);
+    int (*GroupStart)(void);
+    int (*GroupEnd)(void);
+} sh_rccl;
+
+enum { SH_NCCL_INT8 = 0, SH_NCCL_FLOAT32 = 7, SH_NCCL_MAX = 2 };   /* rccl.h: ncclDataType_t, ncclRedOp_t */
+
+static int sh_rccl_load(sh_rccl *R)
+{
+    static const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    size_t i;
+    for (i = 0; i < sizeof(names) / sizeof(names[0]) && !R->lib; i++)
+        R->lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!R->lib) {
+        ERR("sift3d_amd: librccl could not be loaded: %s \n", dlerror());
+        return SIFT3D_FAILURE;
+    }
+#define SH_SYM(field, name)                                             \
+    do {                                                                \
+        *(void **)(&R->field) = dlsym(R->lib, name);                    \
+        if (!R->field) {                                                \
+            ERR("sift3d_amd: librccl lacks %s \n", name);              \
+            return SIFT3D_FAILURE;                                      \
+        }                                                               \
+    } while (0)
+    SH_SYM(GetUniqueId, "ncclGetUniqueId");
+    SH_SYM(CommInitRank, "ncclCommInitRank");
+    SH_SYM(CommDestroy, "ncclCommDestroy");
+    SH_SYM(Send, "ncclSend");
+    SH_SYM(Recv, "ncclRecv");
+    SH_SYM(AllReduce, "ncclAllReduce");
+    SH_SYM(AllGather, "ncclAllGather");
+    SH_SYM(GroupStart, "ncclGroupStart");
+    SH_SYM(GroupEnd, "ncclGroupEnd");
+#undef SH_SYM
+    return SIFT3D_SUCCESS;
+}
+
+static int sh_rccl_halo(void *ctx, const void *send_lo, void *recv_lo, const void *send_hi, void *recv_hi,
+                        size_t bytes, void *stream)
+{
+    sh_rccl *R = (sh_rccl *)ctx;
+    int rc = 0;
+    rc |= R->GroupStart();
+    if (recv_lo) rc |= R->Recv(recv_lo, bytes, SH_NCCL_INT8, R->rank - 1, R->comm, stream);
+    if (recv_hi) rc |= R->Recv(recv_hi, bytes, SH_NCCL_INT8, R->rank + 1, R->comm, stream);
+    if (send_lo) rc |= R->Send(send_lo, bytes, SH_NCCL_INT8, R->rank - 1, R->comm, stream);
+    if (send_hi) rc |= R->Send(send_hi, bytes, SH_NCCL_INT8, R->rank + 1, R->comm, stream);
+    rc |= R->GroupEnd();
+    return rc ? SIFT3D_FAILURE : SIFT3D_SUCCESS;
+}
+
+static int sh_rccl_allreduce_max(void *ctx, float *d_buf, int n, void *stream)
+{
+    sh_rccl *R = (sh_rccl *)ctx;
+    return R->AllReduce(d_buf, d_buf, (size_t)n, SH_NCCL_FLOAT32, SH_NCCL_MAX, R->comm, stream)
+               ? SIFT3D_FAILURE : SIFT3D_SUCCESS;
+}
+
+static int sh_rccl_allgather(void *ctx, const void *d_send, void *d_recv, size_t bytes, void *stream)
+{
+    sh_rccl *R = (sh_rccl *)ctx;
+    return R->AllGather(d_send, d_recv, bytes, SH_NCCL_INT8, R->comm, stream) ? SIFT3D_FAILURE
+                                                                              : SIFT3D_SUCCESS;
+}
+
+int sift3d_amd_rccl_unique_id(void *id128)
+{
+    sh_rccl R;
+    memset(&R, 0, sizeof(R));
+    if (!id128 || sh_rccl_load(&R))
+        return SIFT3D_FAILURE;
+    return R.GetUniqueId((sh_nccl_id *)id128) ? SIFT3D_FAILURE : SIFT3D_SUCCESS;
+}
+
+int sift3d_amd_rccl_transport(sift3d_amd_transport *out, int world, int rank, const void *id128)
+{
+    sh_rccl *R;
+    sh_nccl_id id;
+    if (!out || !id128 || world < 1 || rank < 0 || rank >= world)
+        return SIFT3D_FAILURE;
+    R = (sh_rccl *)calloc(1, sizeof(*R));
+    if (!R || sh_rccl_load(R)) {
+        free(R);
+        return SIFT3D_FAILURE;
+    }
+    memcpy(&id, id128, sizeof(id));
+    R->rank = rank; R->world = world;
+    if (R->CommInitRank(&R->comm, world, id, rank)) {
+        ERR("sift3d_amd: ncclCommInitRank failed (rank %d of %d) \n", rank, world);
+        free(R);
+        return SIFT3D_FAILURE;
+    }
+    memset(out, 0, sizeof(*out));
+    out->rank = rank; out->world = world; out->ctx = R;
+    out->halo = sh_rccl_halo;
+    out->allreduce_max = sh_rccl_allreduce_max;
+    out->allgather = sh_rccl_allgather;
+    return SIFT3D_SUCCESS;
+}
+
+void sift3d_amd_rccl_transport_free(sift3d_amd_transport *t)
+{
+    sh_rccl *R;
+    if (!t || !t->ctx)
+        return;
+    R = (sh_rccl *)t->ctx;
+    if (R->comm)
+        R->CommDestroy(R->comm);
+    free(R);
+    t->ctx = NULL;
+}

@@ -75,6 +75,63 @@ def test_sharded_hip_equals_single_gpu(world, dims, cuboid):
     np.testing.assert_array_equal(covered, 1)
 
 
+def _worker_c(rank, world, port, dims, outdir):
+    """The C slab driver (sift3d_amd_sharded_*) with host-staged gloo exchanges."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from sift3d_amd import api, sharded_c
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
+                            world_size=world)
+    try:
+        nx, ny, nz = dims
+        vol = api.synth_lattice(dims, seed=5)
+        job = sharded_c.CShardedSift3D(nx, ny, nz, sharded_c.DistTransport())
+        z0, z1 = job.in_own
+        job.set_local_volume(vol[z0:z1])
+        job.detect()
+        idx, desc = job.describe()
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), kp=job.keypoints(), idx=idx,
+                 mat=desc.to_mat_rm() if len(idx) else np.zeros((0, 771), np.float32),
+                 ncand=job.ncand, o_shard=job.o_shard)
+        job.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims", [(2, (64, 72, 256)), (3, (48, 48, 320)), (2, (32, 40, 48))])
+def test_c_slab_driver_equals_single_gpu(world, dims):
+    """sift3d_amd_sharded_detect / _describe (host orchestration in C, exchanges through the
+    transport vtable) == the single-GPU drop-in API, bit for bit: sharded octaves, the
+    sharded -> replicated transition, a volume too small to shard at all."""
+    import torch
+    import torch.multiprocessing as mp
+    from sift3d_amd import api
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_c, args=(world, _free_port(), dims, d), nprocs=world, join=True)
+        res = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(world)]
+    vol = api.synth_lattice(dims, seed=5)
+    det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+    assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
+    assert det.extract_descriptors(kp, desc) == 0
+    k = kp.records()
+    m = desc.to_mat_rm()
+    assert len(k) > 5
+    covered = np.zeros(len(k), int)
+    for g in res:
+        assert int(g["ncand"]) == det.num_candidates()
+        for f in ("o", "s", "xd", "yd", "zd", "sd", "strength", "R"):
+            np.testing.assert_array_equal(g["kp"][f], k[f], err_msg=f)
+        np.testing.assert_array_equal(g["mat"], m[g["idx"]])
+        covered[g["idx"]] += 1
+    np.testing.assert_array_equal(covered, 1)
+    assert int(res[0]["o_shard"]) >= (1 if dims[2] >= 200 else 0)
+
+
 def _worker_1024(rank, world, port, n, outdir):
     """BASELINE configs[3] geometry: one 1024^3 volume as `world` Z-slabs.  The slab is generated
     on the device (order-independent generator), results leave the process as digests."""
