@@ -8,7 +8,8 @@ A "step" is one pass of the hot path (sift3d_detect_keypoints + sift3d_extract_d
 through the drop-in C API) over one synthetic float32 volume that is already resident in
 HBM when the timed region starts.  N = 1: the 512^3 volume BASELINE.json's metric is quoted
 on (configs[2]).  N > 1: every rank owns one Z-slab of 512 planes of a 512 x 512 x (512 N)
-volume (weak scaling; halo exchange + keypoint gather over RCCL, sift3d_amd/sharded.py).
+volume (weak scaling; halo exchange + keypoint gather over RCCL, driven by the C slab driver
+sift3d_amd/csrc/sift3d_sharded.c).
 
     python bench.py --gpus N --strong 1024 ...                # BASELINE configs[3]: ONE 1024^3 volume
                                                               # as N Z-slabs (strong scaling)
@@ -216,9 +217,11 @@ def main():
                     help="strong scaling: ONE EDGE^3 volume (BASELINE configs[3]: 1024) cut into "
                          "--gpus Z-slabs, instead of the default 512 planes per GPU")
     ap.add_argument("--no-host", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
+    ap.add_argument("--py-driver", action="store_true",
+                    help="N > 1 / --sharded: use the Python slab driver instead of the C one")
     ap.add_argument("--sharded", action="store_true",
-                    help="N=1 only: run the Z-slab driver (sift3d_amd.sharded) instead of the C API, "
-                         "to measure the driver's own overhead")
+                    help="N=1 only: run the Z-slab driver (C: sift3d_amd_sharded_*) instead of the "
+                         "drop-in API, to measure the driver's own overhead")
     a = ap.parse_args()
 
     import torch
@@ -264,8 +267,26 @@ def main():
                              stage_s={k: round(v, 6) for k, v in det.timings().items()})
         pyr_time = lambda: det.timings()["gauss_dev"]  # noqa: E731
     else:
-        from sift3d_amd import sharded
-        job = sharded.ShardedSift3D(n, n, nz_total, dist.group.WORLD if world > 1 else None)
+        # The slab driver in C (sift3d_amd/csrc/sift3d_sharded.c) over the library's own RCCL
+        # communicator; rehearsals on one device stage the exchanges through gloo.  The Python
+        # driver (sift3d_amd/sharded.py) remains for configurations the C driver refuses.
+        job = None
+        if not a.py_driver:
+            from sift3d_amd import sharded_c
+            try:
+                if world == 1:
+                    tr = None
+                elif rehearse:
+                    tr = sharded_c.DistTransport()
+                else:
+                    tr = sharded_c.RcclTransport()
+                job = sharded_c.CShardedSift3D(n, n, nz_total, tr)
+            except (ValueError, RuntimeError) as e:
+                sys.stderr.write("bench: C slab driver unavailable (%s), using the Python driver\n" % e)
+                job = None
+        if job is None:
+            from sift3d_amd import sharded
+            job = sharded.ShardedSift3D(n, n, nz_total, dist.group.WORLD if world > 1 else None)
         job.synth(seed=11)
         step = job.step
         stats = job.stats
