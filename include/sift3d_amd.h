@@ -356,6 +356,16 @@ SIFT3D_AMD_API int
 sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d_kp,
                     uint32_t n, float *d_hist, void *stream);
 
+/* The same with the Gaussian window weights tabulated per level (they are looked up by the
+ * integer squared voxel distance instead of one division + expf per window voxel; exact for
+ * levels whose spacing is one power of two on all axes, the others fall back).  d_wlut: device
+ * scratch of sift3d_hip_describe_wlut_floats(nlevels) floats, rebuilt by every call; nlevels =
+ * number of entries of d_levels. */
+SIFT3D_AMD_API size_t sift3d_hip_describe_wlut_floats(int nlevels);
+SIFT3D_AMD_API int
+sift3d_hip_describe_wlut(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
+                         uint32_t n, float *d_hist, float *d_wlut, void *stream);
+
 /* Icosahedron face table for the descriptor kernel (init_geometry, sift.c:148-259;
  * per-face constants of cart2bary, sift.c:276-297).  20 records of
  * {v0[3], e1[3], e2[3], t[3], q[3], e2.q, idx[3] (as float)} = 19 floats each. */

@@ -50,7 +50,11 @@ constexpr int DQ = 256; // compaction queue length (power of two, >= 63 + 2 * 64
 // The offsets are 64*rank + {0, 8, 18, 26}[colour] for a proper 4-colouring of the
 // icosahedron's vertices, which puts the 24 bins of any voxel (8 neighbouring cells x the 3
 // vertices of a face) on 24 different banks of the 32 that ds_read_b32/ds_write_b32 use.
+constexpr int HIST_USED = 800;   // bins + colouring gaps
 constexpr int HIST_LDS = 800;
+// face records in LDS: 20 floats apart (16 used), so that the 16-byte reads of lanes holding
+// different faces start on different banks for 16 of the 20 faces
+constexpr int FACE_STRIDE = 20;
 // Phase A -> phase B records, field-major: row f holds field f of half a batch (32 voxels; the
 // records go through LDS half a batch at a time: LDS capacity is what limits the waves per CU).
 // Rows are 36 floats apart: the eight rows that the 24 committer lanes of a half-wave read with
@@ -118,11 +122,53 @@ __device__ __forceinline__ int icos_guess(float rx, float ry, float rz)
     return cls * 8 + (int)(rx < 0.0f) + 2 * (int)(ry < 0.0f) + 4 * (int)(rz < 0.0f);
 }
 
+// Gaussian window weights by squared voxel distance.  A keypoint sits on a voxel, and when the
+// level's spacing is the same power of two u on all axes (every octave of an isotropic volume),
+// the squared distance of a window voxel is EXACTLY k * u^2 in float for the integer
+// k = i^2 + j^2 + l^2 (every term and partial sum is an integer times u^2 below 2^24).  The
+// weight expf(-0.5f * sq / sigma^2) (sift.c:1498: an IEEE division and glibc's expf per voxel)
+// then takes at most rad^2 / u^2 + 1 values per level: they are tabulated per level with exactly
+// that expression and the kernel looks them up by k.  Table of level t: WL_STRIDE floats at
+// t * WL_STRIDE: [0] 1.0f if the level qualifies, [1] the level's sd as float bits (2 floats),
+// entries from [4].
+constexpr int WL_STRIDE = 4096, WL_HEAD = 4;
+
+__global__ __launch_bounds__(256) void k_desc_wlut(const sift3d_hip_level *__restrict__ levels, int nlevels,
+                                                   float *__restrict__ lut)
+{
+    const int t = blockIdx.x;
+    if (t >= nlevels)
+        return;
+    const sift3d_hip_level L = levels[t];
+    float *tab = lut + (size_t)t * WL_STRIDE;
+    const float sigma = (float)(L.sd * 7.071067812);                  // sift.c:1453
+    const float rad = (float)(2.0 * (double)sigma);                   // sift.c:1454
+    const float rad2 = rad * rad, sig2 = sigma * sigma;
+    int e;
+    const float mant = frexpf(L.ux, &e);
+    const float u2 = L.ux * L.ux;
+    const bool ok = L.ux == L.uy && L.ux == L.uz && mant == 0.5f &&
+                    rad2 / u2 < (float)(WL_STRIDE - WL_HEAD - 1) && u2 * (float)WL_STRIDE < 16777216.0f;
+    if (threadIdx.x == 0) {
+        tab[0] = ok ? 1.0f : 0.0f;
+        tab[1] = 0.0f;
+        tab[2] = __int_as_float((int)(__double_as_longlong(L.sd) & 0xffffffffll));
+        tab[3] = __int_as_float((int)(__double_as_longlong(L.sd) >> 32));
+    }
+    if (!ok)
+        return;
+    for (int k = threadIdx.x; k < WL_STRIDE - WL_HEAD; k += 256) {
+        const float sq = (float)k * u2;                               // exact
+        const float arg = -0.5f * sq / sig2;
+        tab[WL_HEAD + k] = arg >= -150.0f ? s3d_expf(arg) : 0.0f;     // (beyond rad^2: never read)
+    }
+}
+
 constexpr int DWAVES = 4;   // keypoints (waves) per workgroup; they share the read-only tables
 
 __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level *__restrict__ levels,
                                                  const sift3d_hip_kp *__restrict__ kps, uint32_t n,
-                                                 float *__restrict__ out DESC_ABLATE_ARG)
+                                                 float *__restrict__ out, const float *__restrict__ wlut DESC_ABLATE_ARG)
 {
     // per wave: 2 * 3200 + 2016 + 1024 B; per workgroup 39.4 KB -> four workgroups = 16 waves per CU
     __shared__ float hist_[DWAVES][2 * HIST_LDS];   // one private histogram per half-wave
@@ -130,7 +176,7 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     __shared__ __attribute__((aligned(16))) float bw_[DWAVES][3][RROW]; // barycentric weights
     __shared__ __attribute__((aligned(16))) int ab_[DWAVES][3][RROW];   // byte address of bin (base cell, face vertex j)
     __shared__ int queue_[DWAVES][DQ];   // xx | yy<<10 | zz<<20, window-relative, in scan order
-    __shared__ __attribute__((aligned(16))) float sface[20 * 16]; // c_face16 (per-lane face index)
+    __shared__ __attribute__((aligned(16))) float sface[20 * FACE_STRIDE]; // c_face16 (per-lane face index)
     __shared__ int soct[32];      // c_oct_face
     __shared__ uint64_t sexp[32]; // s3d_exp2_tab (per-lane index)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -141,7 +187,7 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     int(*const ab)[RROW] = ab_[wv];
     int *const queue = queue_[wv];
     for (int i = threadIdx.x; i < 20 * 16; i += 64 * DWAVES)
-        sface[i] = c_face16[i];
+        sface[(i >> 4) * FACE_STRIDE + (i & 15)] = c_face16[i];
     if (threadIdx.x < 32) {
         soct[threadIdx.x] = c_oct_face[threadIdx.x];
         sexp[threadIdx.x] = s3d_exp2_tab[threadIdx.x];
@@ -155,6 +201,17 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     const sift3d_hip_kp K = kps[ki];
     const sift3d_hip_level L = levels[K.level];
     const uint32_t orow = K.row1 ? K.row1 - 1 : ki;   // output row (launch order may differ)
+    // weight table of the keypoint's level (see k_desc_wlut): usable when the level qualified,
+    // the keypoint carries the level's own scale and sits on a voxel
+    const float *__restrict__ wtab = nullptr;
+    const int icx = (int)K.cx, icy = (int)K.cy, icz = (int)K.cz;
+    if (wlut) {
+        const float *tab = wlut + (size_t)K.level * WL_STRIDE;
+        const long long sdbits = ((long long)__float_as_int(tab[3]) << 32) | (unsigned)__float_as_int(tab[2]);
+        if (tab[0] == 1.0f && sdbits == __double_as_longlong(K.sd) && (float)icx == K.cx &&
+            (float)icy == K.cy && (float)icz == K.cz)
+            wtab = tab + WL_HEAD;                    // wave-uniform
+    }
 
     const float sigma = (float)(K.sd * 7.071067812);                  // sift.c:1453
     const float rad = (float)(2.0 * (double)sigma);                   // sift.c:1454
@@ -175,7 +232,8 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     B.ze = min(B.ze, L.z_off + L.nz - 2);
     // phase B roles: each half-wave commits one voxel per round; its lanes 0..23 are the
     // (trilinear cell corner, face vertex) pairs of that voxel.  Lanes 24..31 repeat lane 0's
-    // work (same address, same value: harmless), which keeps the commit free of predication.
+    // work (same address, same value: harmless; giving them scratch slots of their own measured
+    // MORE bank conflicts), which keeps the commit free of predication.
     const int half = lane >> 5, l5 = lane & 31;
     const int pc = l5 < 24 ? l5 / 3 : 0, pj = l5 < 24 ? l5 - 3 * pc : 0;
     const int pdx = (pc >> 2) & 1, pdy = (pc >> 1) & 1, pdz = pc & 1;
@@ -226,8 +284,15 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         const gfloat_p p = gdata + ((uint64_t)zs32 * (uint32_t)zl + (uint32_t)(x + (int)ys32 * y));
         pv[0] = p[1]; pv[1] = *(p - 1); pv[2] = p[ys32]; pv[3] = *(p - ys32);
         pv[4] = p[zs32]; pv[5] = *(p - zs32);
+        if (wtab) {
+            // the Gaussian weight is a seventh (L2-resident) load, in flight with the samples
+            const int i = x - icx, j = y - icy, l = B.zs + (ppk >> 20) - icz;
+            pv[6] = wtab[i * i + j * j + l * l];
+        }
     };
     auto prefetch_weight = [&]() {
+        if (wtab)
+            return;
         const int x = B.xs + (ppk & 1023), y = B.ys + ((ppk >> 10) & 1023);
         const float dx = ((float)x - K.cx) * L.ux;                 // sift.c:102-104
         const float dy = ((float)y - K.cy) * L.uy;
@@ -328,7 +393,7 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         int fidx = 0;
         float b0 = 0.f, b1 = 0.f, b2 = 0.f;
         const int f0 = soct[icos_guess(rx, ry, rz)];
-        bool found = face_eval(reinterpret_cast<const float4 *>(sface) + f0 * 4, rx, ry, rz, b0, b1,
+        bool found = face_eval(reinterpret_cast<const float4 *>(sface + f0 * FACE_STRIDE), rx, ry, rz, b0, b1,
                                b2, fidx) &&
                      fminf(b0, fminf(b1, b2)) > 2e-5f;
         commit_write(1);
@@ -366,7 +431,7 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
             for (int f = 0; f < 20; f++) {
                 float xb, yb, zb;
                 int fi;
-                const bool hit = face_eval(reinterpret_cast<const float4 *>(sface) + f * 4, rx,
+                const bool hit = face_eval(reinterpret_cast<const float4 *>(sface + f * FACE_STRIDE), rx,
                                            ry, rz, xb, yb, zb, fi);
                 if (open && hit) {
                     b0 = xb; b1 = yb; b2 = zb; fidx = fi;
@@ -488,12 +553,12 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     // double in element order; here every lane sums its 12-13 slots and the 64 partial sums are
     // combined by a fixed butterfly (reproducible; the double sum agrees to ~1e-16 relative).
     const float trunc = 0.2f * 128.0f / 768.0f;                               // sift.c:45
-    for (int i = lane; i < HIST_LDS; i += 64)
+    for (int i = lane; i < HIST_USED; i += 64)
         hist[i] = hist[i] + hist[HIST_LDS + i];
     wave_sync();
     for (int pass = 0; pass < 2; pass++) {
         double norm = 0.0;
-        for (int i = lane; i < HIST_LDS; i += 64) {
+        for (int i = lane; i < HIST_USED; i += 64) {
             const float el = hist[i];                                         // unused slots hold 0
             norm += (double)el * (double)el;
         }
@@ -503,7 +568,7 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         norm = sqrt(norm) + 2.220446049250313e-16;                            // DBL_EPSILON
         const float inv = (float)(1.0 / norm);                                // 1.0f / norm
         wave_sync();
-        for (int i = lane; i < HIST_LDS; i += 64) {
+        for (int i = lane; i < HIST_USED; i += 64) {
             float el = hist[i] * inv;
             if (pass == 0)
                 el = el < trunc ? el : trunc;                                 // sift.c:1520
@@ -640,23 +705,46 @@ int sift3d_hip_set_mesh(const float *faces)
     return SIFT3D_SUCCESS;
 }
 
-int sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d_kp, uint32_t n,
-                        float *d_hist, void *stream)
+size_t sift3d_hip_describe_wlut_floats(int nlevels)
 {
-    if (!n)
-        return SIFT3D_SUCCESS;
+    return nlevels > 0 ? (size_t)nlevels * WL_STRIDE : 0;
+}
+
+static int describe_launch(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d_kp, uint32_t n,
+                           float *d_hist, const float *d_wlut, void *stream)
+{
 #ifdef SIFT3D_AMD_DIAG
     // diagnostic build only (wrong results): 1 skips the commit, 2 the whole batch -- used by
     // profiles/ scripts to attribute the kernel's time to scan / per-voxel terms / commit
     static int ablate = getenv("SIFT3D_AMD_DESC_ABLATE") ? atoi(getenv("SIFT3D_AMD_DESC_ABLATE")) : 0;
     hipLaunchKernelGGL(k_describe, dim3((n + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
-                       (hipStream_t)stream, d_levels, d_kp, n, d_hist, ablate);
+                       (hipStream_t)stream, d_levels, d_kp, n, d_hist, d_wlut, ablate);
 #else
     hipLaunchKernelGGL(k_describe, dim3((n + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
-                       (hipStream_t)stream, d_levels, d_kp, n, d_hist);
+                       (hipStream_t)stream, d_levels, d_kp, n, d_hist, d_wlut);
 #endif
     LAUNCH_CHECK();
     return SIFT3D_SUCCESS;
+}
+
+int sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d_kp, uint32_t n,
+                        float *d_hist, void *stream)
+{
+    if (!n)
+        return SIFT3D_SUCCESS;
+    return describe_launch(d_levels, d_kp, n, d_hist, nullptr, stream);
+}
+
+int sift3d_hip_describe_wlut(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
+                             uint32_t n, float *d_hist, float *d_wlut, void *stream)
+{
+    if (!n)
+        return SIFT3D_SUCCESS;
+    if (!d_wlut || nlevels < 1)
+        return describe_launch(d_levels, d_kp, n, d_hist, nullptr, stream);
+    hipLaunchKernelGGL(k_desc_wlut, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, d_levels, nlevels,
+                       d_wlut);
+    return describe_launch(d_levels, d_kp, n, d_hist, d_wlut, stream);
 }
 
 } // extern "C"

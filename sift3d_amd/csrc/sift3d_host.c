@@ -124,6 +124,7 @@ struct _sift3d_detector {
     int32_t *d_keep, *h_keep;
     void *d_work;
     size_t work_bytes;
+    float *d_wlut;         /* per-level window-weight tables of the descriptor kernel */
     sift3d_hip_kp *d_kp, *h_kp;
     uint32_t kp_cap;
     int have_pyramid;
@@ -883,6 +884,8 @@ static void free_device_pyramid(sift3d_detector *d)
     sift3d_hip_free(d->d_scalars);
     sift3d_hip_free(d->d_levels);
     sift3d_hip_free(d->d_work);
+    sift3d_hip_free(d->d_wlut);
+    d->d_wlut = NULL;
     d->d_im = d->d_tmp_a = d->d_tmp_b = d->d_scalars = NULL;
     d->d_levels = NULL;
     d->d_work = NULL;
@@ -982,7 +985,9 @@ static int resize_detector(sift3d_detector *d)
                                                         (size_t)d->num_octaves * ngl);
     d->d_work = sift3d_hip_malloc(work);
     d->work_bytes = work;
-    if (!d->d_im || !d->d_tmp_a || !d->d_tmp_b || !d->d_scalars || !d->d_levels || !d->d_work)
+    d->d_wlut = (float *)sift3d_hip_malloc(sizeof(float) *
+                                           sift3d_hip_describe_wlut_floats(d->num_octaves * ngl));
+    if (!d->d_wlut || !d->d_im || !d->d_tmp_a || !d->d_tmp_b || !d->d_scalars || !d->d_levels || !d->d_work)
         return SIFT3D_FAILURE;
     return build_filters(d);
 }
@@ -1594,7 +1599,8 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
      * pays the kernel's long tail.) */
     {
         float *dev_view = (float *)sift3d_hip_host_device_ptr(desc->hist);
-        if (!dev_view || sift3d_hip_describe(d->d_levels, d->d_kp, (uint32_t)num, dev_view, d->stream))
+        if (!dev_view || sift3d_hip_describe_wlut(d->d_levels, d->num_octaves * d->ngl, d->d_kp,
+                                                  (uint32_t)num, dev_view, d->d_wlut, d->stream))
             return SIFT3D_FAILURE;
     }
     sift3d_hip_event_record(d->ev[7], d->stream);

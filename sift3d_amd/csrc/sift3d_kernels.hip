@@ -1424,6 +1424,30 @@ __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restric
     __shared__ int queue[256];   // in-sphere voxels, window relative, in scan order
     uint32_t qhead = 0, qtail = 0;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // Gaussian window weights.  The centre is a voxel, and when the level's spacing is the same
+    // power of two u on all axes (every octave of an isotropic volume) the squared distance of a
+    // window voxel is EXACTLY k * u^2 in float for the integer k = i^2 + j^2 + l^2 (each term and
+    // each partial sum is an integer times u^2 below 2^24).  So the weight, expf of a double
+    // division per voxel in the reference (sift.c:972), takes at most rad^2 / u^2 + 1 values,
+    // which are tabulated once per candidate with the reference's expression and looked up by k.
+    constexpr int WLUT = 192;
+    __shared__ float wlut[WLUT];
+    bool use_lut = false;
+    {
+        int e;
+        const float mant = frexpf(L.ux, &e);
+        const float u2 = L.ux * L.ux;
+        const double kmax = rad2 / (double)u2;
+        if (L.ux == L.uy && L.ux == L.uz && mant == 0.5f && kmax < (double)(WLUT - 1) &&
+            u2 * (float)WLUT < 16777216.0f) {                     // wave-uniform
+            use_lut = true;
+            for (int k = lane; k < WLUT; k += 64) {
+                const float sq = (float)k * u2;                   // exact
+                wlut[k] = s3d_expf((float)(-0.5 * (double)sq / sig2));   // sift.c:972
+            }
+        }
+    }
+    __syncthreads();
 
     // 64 queued (in-sphere) voxels: their nine terms in parallel, then added in voxel order by
     // the nine accumulator lanes.  Lanes beyond `cnt` contribute exact zeros (a no-op).
@@ -1433,11 +1457,16 @@ __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restric
         if (in) {
             const int pk = queue[(qhead + lane) & 255];
             const int x = B.xs + (pk & 1023), y = B.ys + ((pk >> 10) & 1023), z = B.zs + (pk >> 20);
-            const float dx = ((float)x - cx) * L.ux;              // sift.c:102-104
-            const float dy = ((float)y - cy) * L.uy;
-            const float dz = ((float)z - cz) * L.uz;
-            const float sq = dx * dx + dy * dy + dz * dz;         // sift.c:105
-            w = s3d_expf((float)(-0.5 * (double)sq / sig2));      // sift.c:972
+            if (use_lut) {
+                const int i = x - kx, j = y - ky, l = z - kz;
+                w = wlut[min(i * i + j * j + l * l, WLUT - 1)];   // (in-sphere: k <= rad^2 / u^2)
+            } else {
+                const float dx = ((float)x - cx) * L.ux;          // sift.c:102-104
+                const float dy = ((float)y - cy) * L.uy;
+                const float dz = ((float)z - cz) * L.uz;
+                const float sq = dx * dx + dy * dy + dz * dz;     // sift.c:105
+                w = s3d_expf((float)(-0.5 * (double)sq / sig2));  // sift.c:972
+            }
             grad_iso(L, x, y, z - L.z_off, gx, gy, gz);
         }
         // sift.c:978-987

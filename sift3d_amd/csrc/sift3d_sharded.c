@@ -75,6 +75,7 @@ struct sift3d_amd_sharded {
     sift3d_hip_level h_levels[SH_MAX_OCT * SH_NGL], *d_levels;
     void *d_work;
     size_t work_bytes;
+    float *d_wlut;
     sift3d_hip_cand *d_cand, *h_cand;
     float *d_R, *h_R;
     int32_t *d_keep, *h_keep;
@@ -161,7 +162,7 @@ void sift3d_amd_sharded_free(sift3d_amd_sharded *S)
     sift3d_hip_free(S->d_raw); sift3d_hip_free(S->d_stage); sift3d_hip_free(S->d_scalars);
     sift3d_hip_free(S->d_levels); sift3d_hip_free(S->d_work); sift3d_hip_free(S->d_cand);
     sift3d_hip_free(S->d_R); sift3d_hip_free(S->d_keep); sift3d_hip_free(S->d_xchg);
-    sift3d_hip_free(S->d_kp);
+    sift3d_hip_free(S->d_kp); sift3d_hip_free(S->d_wlut);
     sift3d_hip_host_free(S->h_cand); sift3d_hip_host_free(S->h_R); sift3d_hip_host_free(S->h_keep);
     sift3d_hip_host_free(S->h_xchg); sift3d_hip_host_free(S->h_kp);
     sift3d_hip_event_destroy(S->ev_x); sift3d_hip_event_destroy(S->ev_halo);
@@ -294,7 +295,9 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
     S->d_levels = (sift3d_hip_level *)sift3d_hip_malloc(sizeof(sift3d_hip_level) * SH_MAX_OCT * SH_NGL);
     S->d_work = sift3d_hip_malloc(work);
     S->work_bytes = work;
-    if (!S->d_tmp_a || !S->d_tmp_b || !S->d_im || !S->d_raw || !S->d_stage || !S->d_scalars ||
+    S->d_wlut = (float *)sift3d_hip_malloc(sizeof(float) *
+                                           sift3d_hip_describe_wlut_floats(S->num_octaves * SH_NGL));
+    if (!S->d_wlut || !S->d_tmp_a || !S->d_tmp_b || !S->d_im || !S->d_raw || !S->d_stage || !S->d_scalars ||
         !S->d_levels || !S->d_work)
         goto fail;
     /* level table (window kernels) */
@@ -846,7 +849,8 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
         float *dev_view = (float *)sift3d_hip_host_device_ptr(desc->hist);
         if (!dev_view ||
             sift3d_hip_memcpy_h2d(S->d_kp, S->h_kp, sizeof(sift3d_hip_kp) * (size_t)n, S->stream) ||
-            sift3d_hip_describe(S->d_levels, S->d_kp, (uint32_t)n, dev_view, S->stream) ||
+            sift3d_hip_describe_wlut(S->d_levels, S->num_octaves * SH_NGL, S->d_kp, (uint32_t)n, dev_view,
+                                     S->d_wlut, S->stream) ||
             sift3d_hip_stream_sync(S->stream))
             return SIFT3D_FAILURE;
     }
