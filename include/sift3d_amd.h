@@ -114,6 +114,39 @@ SIFT3D_AMD_API int sift3d_amd_device_available(void);
 SIFT3D_AMD_API const char *sift3d_amd_version(void);
 
 /* ------------------------------------------------------------------------ */
+/* Registration: descriptor matching + RANSAC affine (BASELINE config 5)     */
+/* ------------------------------------------------------------------------ */
+/* Removed from the reference fork (CHANGES.md:99-103; upstream: README-OLD.md:5) -- no reference
+ * code, no oracle: PARITY UNPINNED.  See sift3d_amd/csrc/sift3d_register.c. */
+
+/* Nearest / second-nearest neighbour of each of the nA rows of d_A (nA x dim floats, row-major)
+ * among the nB rows of d_B under the squared L2 distance, on the matrix cores
+ * (v_mfma_f32_32x32x2_f32).  d_j1[i] = index of the nearest row (-1: nB == 0), d_d1 / d_d2 =
+ * squared distances to the nearest and second nearest (+inf when absent).  dim % 16 == 0.
+ * d_work: sift3d_hip_nn2_work_floats(nA, nB) floats of device scratch. */
+SIFT3D_AMD_API size_t sift3d_hip_nn2_work_floats(int nA, int nB);
+SIFT3D_AMD_API int
+sift3d_hip_nn2(const float *d_A, int nA, const float *d_B, int nB, int dim, int *d_j1, float *d_d1,
+               float *d_d2, float *d_work, void *stream);
+
+/* match_ab[i] (i < size of a) = index in b of the descriptor matched to descriptor i of a, or -1:
+ * nearest neighbour accepted when (nearest distance) / (second nearest) < nn_thresh (e.g. 0.8)
+ * in BOTH directions and mutual. */
+SIFT3D_AMD_API int
+sift3d_amd_nn_match(const sift3d_descriptor_store *a, const sift3d_descriptor_store *b,
+                    double nn_thresh, int *match_ab);
+SIFT3D_AMD_API int
+sift3d_amd_descriptor_store_xyz(const sift3d_descriptor_store *, int i, double *xyz /*3*/);
+
+/* RANSAC fit of the affine map dst = A [src; 1] (tform: 3 x 4 doubles, row-major) to n point
+ * pairs (n x 3 doubles each): num_iter minimal samples of 4 pairs, inliers = residual <=
+ * err_thresh, least-squares refit on the best consensus set.  inlier (n bytes, may be NULL)
+ * receives 0 / 1.  Deterministic for a given seed. */
+SIFT3D_AMD_API int
+sift3d_amd_ransac_affine(const double *src, const double *dst, int n, double err_thresh, int num_iter,
+                         uint64_t seed, double *tform, unsigned char *inlier, int *num_inliers);
+
+/* ------------------------------------------------------------------------ */
 /* Multi-GPU: one process per GPU, the volume cut into Z-slabs               */
 /* ------------------------------------------------------------------------ */
 

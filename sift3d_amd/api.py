@@ -81,6 +81,11 @@ def lib():
         "sift3d_amd_keypoint_store_set": (C.c_int, [vp, C.c_int, _i32p, _f64p, _f32p, _f32p]),
         "sift3d_amd_descriptor_store_size": (C.c_int, [vp]),
         "sift3d_amd_descriptor_store_set": (C.c_int, [vp, C.c_int, _f64p, _f32p, C.c_int, C.c_int, C.c_int]),
+        "sift3d_amd_nn_match": (C.c_int, [vp, vp, C.c_double, _i32p]),
+        "sift3d_amd_descriptor_store_xyz": (C.c_int, [vp, C.c_int, _f64p]),
+        "sift3d_amd_ransac_affine": (C.c_int, [_f64p, _f64p, C.c_int, C.c_double, C.c_int, C.c_uint64,
+                                              _f64p, np.ctypeslib.ndpointer(np.uint8),
+                                              C.POINTER(C.c_int)]),
         "sift3d_amd_device_available": (C.c_int, []),
         "sift3d_amd_version": (C.c_char_p, []),
         "sift3d_amd_synth_survey": (None, [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64]),
@@ -383,3 +388,27 @@ def gauss_filter(sigma):
     if w < 1 or w > 1024:
         raise ValueError("gauss_filter(%r)" % sigma)
     return taps[:w].copy()
+
+
+# ---- registration (BASELINE config 5; parity unpinned: removed from the reference fork) --------
+def nn_match(desc_a, desc_b, nn_thresh=0.8):
+    """match[i] = index in desc_b of the descriptor matched to descriptor i of desc_a, or -1."""
+    out = np.full(max(len(desc_a), 1), -1, np.int32)
+    if lib().sift3d_amd_nn_match(desc_a.h, desc_b.h, float(nn_thresh), out) != 0:
+        raise RuntimeError("sift3d_amd_nn_match failed")
+    return out[:len(desc_a)]
+
+
+def ransac_affine(src, dst, err_thresh=5.0, num_iter=500, seed=1):
+    """Affine map dst = A [src; 1]: returns (A 3x4, inlier mask)."""
+    src = np.ascontiguousarray(src, np.float64).reshape(-1, 3)
+    dst = np.ascontiguousarray(dst, np.float64).reshape(-1, 3)
+    assert len(src) == len(dst)
+    A = np.zeros(12, np.float64)
+    inl = np.zeros(max(len(src), 1), np.uint8)
+    cnt = C.c_int()
+    rc = lib().sift3d_amd_ransac_affine(src.reshape(-1), dst.reshape(-1), len(src), float(err_thresh),
+                                        int(num_iter), int(seed), A, inl, C.byref(cnt))
+    if rc != 0:
+        raise RuntimeError("sift3d_amd_ransac_affine: no model")
+    return A.reshape(3, 4), inl[:len(src)].astype(bool)

@@ -1659,3 +1659,6 @@ int sift3d_amd_copy_level(const sift3d_detector *d, int which, int o, int s, flo
 
 /* the Z-slab multi-GPU driver (uses the private layouts above) */
 #include "sift3d_sharded.c"
+
+/* descriptor matching + RANSAC affine (BASELINE config 5) */
+#include "sift3d_register.c"

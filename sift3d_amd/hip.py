@@ -73,6 +73,8 @@ def lib():
         "sift3d_hip_fir": (C.c_int, [C.POINTER(FirArgs), vp]),
         "sift3d_hip_fir_yz_u1": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+        "sift3d_hip_nn2_work_floats": (C.c_size_t, [C.c_int, C.c_int]),
+        "sift3d_hip_nn2": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
         "sift3d_hip_subtract_absmax": (C.c_int, [vp, vp, vp, C.c_size_t, vp, vp]),
         "sift3d_hip_dog_stack": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_size_t, vp, vp]),
         "sift3d_hip_host_device_ptr": (vp, [vp]),
@@ -143,6 +145,22 @@ def fir_yz(src, dst, taps, n_glob=None, off=0, z_lo=0, z_hi=None):
         return False
     _check(rc, "sift3d_hip_fir_yz_u1")
     return True
+
+
+def nn2(a, b):
+    """Nearest / second-nearest row of b for every row of a (CUDA float32 tensors [n, dim]):
+    returns (index int32, squared distance, second squared distance) as tensors."""
+    import torch
+    assert a.is_contiguous() and b.is_contiguous() and a.shape[1] == b.shape[1]
+    na, nb = a.shape[0], b.shape[0]
+    j = torch.empty(max(na, 1), dtype=torch.int32, device=a.device)
+    d1 = torch.empty(max(na, 1), dtype=torch.float32, device=a.device)
+    d2 = torch.empty_like(d1)
+    work = torch.empty(lib().sift3d_hip_nn2_work_floats(na, nb), dtype=torch.float32, device=a.device)
+    _check(lib().sift3d_hip_nn2(a.data_ptr(), na, b.data_ptr(), nb, a.shape[1], j.data_ptr(),
+                                d1.data_ptr(), d2.data_ptr(), work.data_ptr(), current_stream()),
+           "sift3d_hip_nn2")
+    return j[:na], d1[:na], d2[:na]
 
 
 def absmax(src, out):
