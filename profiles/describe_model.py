@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Issue-rate model of k_describe (profiles/describe_model.json, read by bench.py).
+
+    # on the GPU box (cd /tmp && export TMPDIR=/tmp first), three runs of this script:
+    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d gpurun_out/pmc_desc/a -o run --output-format csv -- python3 profiles/describe_model.py --run
+    rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES -d gpurun_out/pmc_desc/b -o run --output-format csv -- python3 profiles/describe_model.py --run
+    python3 profiles/describe_model.py --count          # diagnostic build: exact window voxels
+    python3 profiles/describe_model.py --parse gpurun_out/pmc_desc <window_voxels> > profiles/describe_model.json
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(n=512):
+    import torch
+    from sift3d_amd import api, hip
+    vol = torch.empty((n, n, n), device="cuda")
+    hip.synth_lattice(vol, 0, 11)
+    det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+    assert det.detect_keypoints_device(vol.data_ptr(), n, n, n, kp) == 0
+    assert det.extract_descriptors(kp, desc) == 0
+    return det, kp, desc
+
+
+def count():
+    """Needs the diagnostic build (scratch/mkdiag.sh) in place of the library."""
+    import ctypes as C
+    from sift3d_amd import api
+    L = api.lib()
+    L.sift3d_amd_diag_desc_voxels.restype = C.c_ulonglong
+    L.sift3d_amd_diag_desc_voxels()
+    det, kp, desc = run()
+    print(json.dumps(dict(window_voxels=int(L.sift3d_amd_diag_desc_voxels()), keypoints=len(kp))))
+
+
+def parse(d, voxels):
+    agg = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "k_describe" in r["Kernel_Name"]:
+                agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    c = {k: sum(v) / len(v) for k, v in agg.items()}
+    out = dict(kernel="k_describe", workload="512^3 lattice volume, 42 501 keypoints", window_voxels=int(voxels),
+               valu_insts=c.get("SQ_INSTS_VALU"), salu_insts=c.get("SQ_INSTS_SALU"),
+               lds_insts=c.get("SQ_INSTS_LDS"), lds_array_cycles=c.get("SQ_LDS_IDX_ACTIVE"),
+               lds_bank_conflict_cycles=c.get("SQ_LDS_BANK_CONFLICT"), waves=c.get("SQ_WAVES"),
+               cycles_per_valu=2.5,
+               note="wave-instructions per launch (rocprofv3 --pmc); one VALU instruction occupies a "
+                    "SIMD for ~2.5 cycles (scratch microbenchmark, plain f32 ops); "
+                    "lds_array_cycles is summed over the 256 CUs")
+    if voxels and c.get("SQ_INSTS_VALU"):
+        out["valu_insts_per_64_voxels"] = round(64.0 * c["SQ_INSTS_VALU"] / voxels, 1)
+        out["lds_insts_per_64_voxels"] = round(64.0 * c.get("SQ_INSTS_LDS", 0) / voxels, 1)
+        out["lds_array_cycles_per_64_voxels"] = round(64.0 * c.get("SQ_LDS_IDX_ACTIVE", 0) / voxels, 1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    if "--run" in sys.argv:
+        run()
+    elif "--count" in sys.argv:
+        count()
+    elif "--parse" in sys.argv:
+        i = sys.argv.index("--parse")
+        parse(sys.argv[i + 1], float(sys.argv[i + 2]))

@@ -64,6 +64,7 @@ constexpr int RROW = 36;
 #ifdef SIFT3D_AMD_DIAG
 #define DESC_ABLATE_ARG , int ablate
 #define DESC_ABLATE(bit) (ablate & (bit))
+__device__ unsigned long long g_desc_voxels;   // window voxels committed (profiles/ model)
 #else
 #define DESC_ABLATE_ARG
 #define DESC_ABLATE(bit) false
@@ -362,6 +363,10 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     // and with the sample requests of the next one (ncnt voxels from queue position nstart;
     // ncnt may be 0); then this batch's records take the previous one's place.
     auto batch = [&](int cnt, const float *cv, int pk, uint32_t nstart, int ncnt) {
+#ifdef SIFT3D_AMD_DIAG
+        if (lane == 0)
+            atomicAdd(&g_desc_voxels, (unsigned long long)cnt);
+#endif
         prefetch_loads(nstart, ncnt);
         if (DESC_ABLATE(2)) { prefetch_weight(); return; }
         commit_write(0);
@@ -704,6 +709,18 @@ int sift3d_hip_set_mesh(const float *faces)
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_oct_face), oct, sizeof(oct)));
     return SIFT3D_SUCCESS;
 }
+
+#ifdef SIFT3D_AMD_DIAG
+// diagnostic build only: window voxels committed since the last call
+__attribute__((visibility("default"))) unsigned long long sift3d_amd_diag_desc_voxels(void)
+{
+    unsigned long long v = 0, z = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_desc_voxels), sizeof(v));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_desc_voxels), &z, sizeof(z));
+    return v;
+}
+#endif
 
 size_t sift3d_hip_describe_wlut_floats(int nlevels)
 {
