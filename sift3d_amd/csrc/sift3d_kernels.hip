@@ -1419,8 +1419,10 @@ __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restric
     B.ze = min(B.ze, L.z_off + L.nz - 2);
     double dacc = 0.0; // lanes 0..5: A00 A01 A02 A11 A12 A22
     float facc = 0.0f; // lanes 6..8: vd_win x y z
-    const double *tdp = td[lane < 6 ? lane : 0];
-    const float *tfp = tf[lane >= 6 && lane < 9 ? lane - 6 : 0];
+    // accumulator lane -> its row of terms and the bytes per voxel in it
+    const char *arow = lane < 6 ? reinterpret_cast<const char *>(td[lane])
+                                : reinterpret_cast<const char *>(tf[lane < 9 ? lane - 6 : 0]);
+    const int astride = lane < 6 ? 8 : 4;
     __shared__ int queue[256];   // in-sphere voxels, window relative, in scan order
     uint32_t qhead = 0, qtail = 0;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -1480,34 +1482,44 @@ __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restric
         tf[1][lane] = in ? gy * w : 0.0f;
         tf[2][lane] = in ? gz * w : 0.0f;
         __syncthreads();
-        // Every lane runs both serial sums (the double and the float chain interleave and hide
-        // each other's latency); only lanes 0..5 / 6..8 hold meaningful rows.
+        // The nine accumulator lanes run both serial sums (the double and the float chain
+        // interleave and hide each other's latency; only lanes 0..5 / 6..8 hold meaningful rows).
+        // The other lanes are masked off, and one pair of 16-byte reads serves both kinds of
+        // row (4 voxels of a double row are 32 bytes, of a float row the first 16 of them): an
+        // LDS read costs by the instruction and by the bytes it moves.
+        if (lane < 9) {
 #pragma unroll
-        for (int j = 0; j < 64; j += 4) {
-            const double2 d01 = *reinterpret_cast<const double2 *>(&tdp[j]);
-            const double2 d23 = *reinterpret_cast<const double2 *>(&tdp[j + 2]);
-            const float4 f4 = *reinterpret_cast<const float4 *>(&tfp[j]);
-            dacc += d01.x; facc += f4.x;
-            dacc += d01.y; facc += f4.y;
-            dacc += d23.x; facc += f4.z;
-            dacc += d23.y; facc += f4.w;
+            for (int j = 0; j < 64; j += 4) {
+                const uint4 u0 = *reinterpret_cast<const uint4 *>(arow + (size_t)j * astride);
+                const uint4 u1 = *reinterpret_cast<const uint4 *>(arow + (size_t)j * astride + 16);
+                dacc += __hiloint2double((int)u0.y, (int)u0.x); facc += __uint_as_float(u0.x);
+                dacc += __hiloint2double((int)u0.w, (int)u0.z); facc += __uint_as_float(u0.y);
+                dacc += __hiloint2double((int)u1.y, (int)u1.x); facc += __uint_as_float(u0.z);
+                dacc += __hiloint2double((int)u1.w, (int)u1.z); facc += __uint_as_float(u0.w);
+            }
         }
         __syncthreads();
     };
 
-    // Only the (conservative: +1 voxel, +0.1 %) bounding rectangle of each plane's disc is
-    // scanned; the exact per-voxel test (sift.c:106) and the scan order are unchanged.
+    // Only the (conservative: +0.1 %, against float error of at most 1e-5 relative) bounding
+    // rectangle of each plane's disc is scanned; the exact per-voxel test (sift.c:106) and the scan
+    // order are unchanged.
     const float rad2f = (float)rad2;
     for (int z = B.zs; z <= B.ze; z++) {
         const float dz = ((float)z - cz) * L.uz;
         const float rz = sqrtf(fmaxf(rad2f - dz * dz, 0.0f)) * 1.001f;
-        const float xr = rz / L.ux + 1.0f, yr = rz / L.uy + 1.0f;
+        const float xr = rz / L.ux, yr = rz / L.uy;
         const int pxs = max(B.xs, (int)floorf(cx - xr)), pxe = min(B.xe, (int)ceilf(cx + xr));
         const int pys = max(B.ys, (int)floorf(cy - yr)), pye = min(B.ye, (int)ceilf(cy + yr));
         const int pbx = pxe - pxs + 1, pby = pye - pys + 1;
         const int ppl = pbx > 0 && pby > 0 ? pbx * pby : 0;
         const int ox = pxs - B.xs, oy = pys - B.ys;
-        int yy = pbx > 0 ? lane / pbx : 0, xx = pbx > 0 ? lane - yy * pbx : 0;
+        // lane -> (row, column) of the rectangle, then 64 further per chunk.  The quotients come
+        // from a float reciprocal: (i + 0.5) / pbx is at least 0.5 / pbx away from an integer, far
+        // more than the rounding error for i <= 64 and pbx <= 1024, so the floor is exact.
+        const float rpbx = 1.0f / (float)max(pbx, 1);
+        int yy = (int)(((float)lane + 0.5f) * rpbx), xx = lane - yy * pbx;
+        const int q64 = (int)(64.5f * rpbx), r64 = 64 - q64 * pbx;
         for (int c0 = 0; c0 < ppl; c0 += 64) {
             bool in = false;
             int pk = 0;
@@ -1518,8 +1530,9 @@ __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restric
                 in = !((double)sq > rad2);                        // sift.c:106 (double)
                 pk = (ox + xx) | ((oy + yy) << 10) | ((z - B.zs) << 20);
             }
-            xx += 64;
-            while (xx >= pbx) {
+            xx += r64;
+            yy += q64;
+            if (xx >= pbx) {
                 xx -= pbx;
                 yy++;
             }
