@@ -202,3 +202,54 @@ def test_config4_1024_sharded_equals_single_gpu():
     np.testing.assert_array_equal(covered, 1)
     del det, vol
     torch.cuda.empty_cache()
+
+
+def _worker_rccl1(rank, world, port, dims, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from sift3d_amd import api, sharded_c
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
+                            world_size=world)
+    try:
+        nx, ny, nz = dims
+        vol = api.synth_lattice(dims, seed=5)
+        tr = sharded_c.RcclTransport()
+        job = sharded_c.CShardedSift3D(nx, ny, nz, tr)
+        job.set_local_volume(vol)
+        job.detect()
+        idx, desc = job.describe()
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), kp=job.keypoints(), idx=idx,
+                 mat=desc.to_mat_rm(), ncand=job.ncand)
+        job.close()
+        tr.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_transport_one_rank():
+    """The library's own RCCL transport (librccl loaded with dlopen, communicator from a unique
+    id, ncclAllReduce / ncclAllGather on the driver's stream) on a communicator of ONE rank --
+    all the GPU box can host; the exchanges between ranks themselves are covered by the gloo
+    runs above, the RCCL calls by this one.  Result == the single-GPU API."""
+    import torch
+    import torch.multiprocessing as mp
+    from sift3d_amd import api
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    dims = (64, 72, 96)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_rccl1, args=(1, _free_port(), dims, d), nprocs=1, join=True)
+        g = np.load(os.path.join(d, "rank0.npz"))
+    vol = api.synth_lattice(dims, seed=5)
+    det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+    assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
+    assert det.extract_descriptors(kp, desc) == 0
+    k = kp.records()
+    assert len(k) > 5 and int(g["ncand"]) == det.num_candidates()
+    for f in ("o", "s", "xd", "yd", "zd", "sd", "strength", "R"):
+        np.testing.assert_array_equal(g["kp"][f], k[f], err_msg=f)
+    np.testing.assert_array_equal(g["idx"], np.arange(len(k)))
+    np.testing.assert_array_equal(g["mat"], desc.to_mat_rm())
