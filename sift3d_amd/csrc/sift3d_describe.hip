@@ -173,9 +173,9 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
 {
     // per wave: 2 * 3200 + 2016 + 1024 B; per workgroup 39.4 KB -> four workgroups = 16 waves per CU
     __shared__ float hist_[DWAVES][2 * HIST_LDS];   // one private histogram per half-wave
-    __shared__ __attribute__((aligned(16))) float mw_[DWAVES][8][RROW]; // mag * trilinear weight of the eight cells
-    __shared__ __attribute__((aligned(16))) float bw_[DWAVES][3][RROW]; // barycentric weights
-    __shared__ __attribute__((aligned(16))) int ab_[DWAVES][3][RROW];   // byte address of bin (base cell, face vertex j)
+    // records of half a batch, field-major: rows 0..7 mag * trilinear weight of the eight cells,
+    // 8..10 barycentric weights, 11..13 byte address of bin (base cell, face vertex j)
+    __shared__ __attribute__((aligned(16))) float rec_[DWAVES][14][RROW];
     __shared__ int queue_[DWAVES][DQ];   // xx | yy<<10 | zz<<20, window-relative, in scan order
     __shared__ __attribute__((aligned(16))) float sface[20 * FACE_STRIDE]; // c_face16 (per-lane face index)
     __shared__ int soct[32];      // c_oct_face
@@ -183,9 +183,9 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     float *const hist = hist_[wv];
-    float(*const mw)[RROW] = mw_[wv];
-    float(*const bw)[RROW] = bw_[wv];
-    int(*const ab)[RROW] = ab_[wv];
+    float(*const mw)[RROW] = &rec_[wv][0];
+    float(*const bw)[RROW] = &rec_[wv][8];
+    int(*const ab)[RROW] = reinterpret_cast<int(*)[RROW]>(&rec_[wv][11]);
     int *const queue = queue_[wv];
     for (int i = threadIdx.x; i < 20 * 16; i += 64 * DWAVES)
         sface[(i >> 4) * FACE_STRIDE + (i & 15)] = c_face16[i];
@@ -309,8 +309,11 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     // Records of the batch that is being committed, one voxel per lane: mag * trilinear weight
     // of the eight cells, the three barycentric weights, the three bin addresses.  Empty records
     // (zero weight, bin address 0) add 0 to a valid bin.
-    float rmw[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, rbw[3] = { 0.f, 0.f, 0.f };
-    int rab[3] = { 0, 0, 0 };
+    // An LDS write costs by the instruction and the dwords per lane, whatever the number of
+    // active lanes (scratch/mb/lds_cost.hip), so all 64 lanes write in both passes: the 14 fields
+    // are traded between the half-waves (v_permlane32_swap) so that lane l holds, for voxel l & 31
+    // of each half-batch, fields 0..6 (l < 32) or 7..13 (l >= 32): rp[pass][i].
+    float rp[2][7] = { { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f } };
     // One commit pass: the records of half a batch (voxels 32 * pass .. 32 * pass + 31) go to
     // LDS, field-major, then round u adds voxel u of them (half-wave 0) and voxel 16 + u
     // (half-wave 1), each into its half-wave's own histogram.  The 24 lanes of a voxel own 24
@@ -322,17 +325,11 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     // almost no VALU, so each pass is issued in one basic block with half of the arithmetic of
     // the NEXT batch (see batch()), which the scheduler interleaves with it.  Records of four
     // rounds are read with three 16-byte loads, one chunk ahead.
+    float *const rrow = &rec_[wv][7 * half][l5];
     auto commit_write = [&](int pass) {
-        if (half == pass) {
 #pragma unroll
-            for (int c = 0; c < 8; c++)
-                mw[c][l5] = rmw[c];
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                bw[j][l5] = rbw[j];
-                ab[j][l5] = rab[j];
-            }
-        }
+        for (int i = 0; i < 7; i++)
+            rrow[i * RROW] = rp[pass][i];
         wave_sync();
     };
     auto commit_rounds = [&]() {
@@ -359,7 +356,7 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         }
     };
     // One batch: phase A of `cnt` (<= 64) voxels whose samples were fetched one batch ago (cv,
-    // pk), overlapped with the two commit passes of the previous batch (records in rmw/rbw/rab)
+    // pk), overlapped with the two commit passes of the previous batch (records in rp)
     // and with the sample requests of the next one (ncnt voxels from queue position nstart;
     // ncnt may be 0); then this batch's records take the previous one's place.
     auto batch = [&](int cnt, const float *cv, int pk, uint32_t nstart, int ncnt) {
@@ -449,15 +446,25 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         }
         // this batch's records (voxels without a contribution: zero weights, bin address 0)
         const bool ok = live && found;
+        float fld[14];
 #pragma unroll
         for (int c = 0; c < 8; c++)
-            rmw[c] = ok ? mwv[c] : 0.0f;
-        rbw[0] = ok ? b0 : 0.0f; rbw[1] = ok ? b1 : 0.0f; rbw[2] = ok ? b2 : 0.0f;   // (0 * NaN would be NaN)
+            fld[c] = ok ? mwv[c] : 0.0f;
+        fld[8] = ok ? b0 : 0.0f; fld[9] = ok ? b1 : 0.0f; fld[10] = ok ? b2 : 0.0f;   // (0 * NaN would be NaN)
         // byte addresses of the bins (base cell, face vertex j) -- the vertices addressed
         // through the UNSWAPPED idx[] of the face (quirk Q1)
 #pragma unroll
         for (int j = 0; j < 3; j++)
-            rab[j] = ok ? 4 * ((fidx >> (10 * j)) & 1023) + cell4 : 0;
+            fld[11 + j] = __int_as_float(ok ? 4 * ((fidx >> (10 * j)) & 1023) + cell4 : 0);
+        // swap(a, b): first result = a of lanes 0..31 | b of lanes 0..31, second = a of lanes
+        // 32..63 | b of lanes 32..63
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(fld[i]), __float_as_uint(fld[7 + i]),
+                                                            false, false);
+            rp[0][i] = __uint_as_float(r[0]);
+            rp[1][i] = __uint_as_float(r[1]);
+        }
     };
 
     // The reference scans the whole bounding box of the sphere (sift.c:96-108).  Every voxel
