@@ -411,8 +411,16 @@ def main():
                     simd_rate = 256 * 4 * 2.4e9 / dm.get("cycles_per_valu", 2.5)
                     dm["achieved_valu_insts_per_s"] = round(dm["valu_insts"] / dsec, 1)
                     dm["peak_valu_insts_per_s"] = round(simd_rate, 1)
-                    dm["frac"] = round(dm["valu_insts"] / dsec / simd_rate, 4)
+                    dm["valu_frac"] = round(dm["valu_insts"] / dsec / simd_rate, 4)
                     dm["seconds"] = dsec
+                    lm = dm.get("lds_issue_model") or {}
+                    if lm.get("seconds_if_lds_bound"):
+                        # the binding resource: LDS instruction issue (profiles/microbench/lds_cost.hip)
+                        dm["bound"] = "lds-issue"
+                        dm["frac"] = round(lm["seconds_if_lds_bound"] / dsec, 4)
+                    else:
+                        dm["bound"] = "valu-issue"
+                        dm["frac"] = dm["valu_frac"]
                     out["roofline"]["describe"] = dm
             except Exception:
                 pass

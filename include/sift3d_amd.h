@@ -220,6 +220,7 @@ SIFT3D_AMD_API int sift3d_hip_memcpy2d_d2h(void *h_dst, size_t dst_pitch, const 
 SIFT3D_AMD_API int sift3d_hip_stream_wait_event(void *stream, void *ev);
 SIFT3D_AMD_API int sift3d_hip_memset(void *d_dst, int byte, size_t bytes, void *stream);
 SIFT3D_AMD_API void *sift3d_hip_stream_create(void);
+SIFT3D_AMD_API void *sift3d_hip_stream_create_high(void);   /* highest dispatch priority */
 SIFT3D_AMD_API void sift3d_hip_stream_destroy(void *stream);
 SIFT3D_AMD_API int sift3d_hip_stream_sync(void *stream);
 /* HIP events, for device-side stage timing */

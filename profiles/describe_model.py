@@ -58,6 +58,25 @@ def parse(d, voxels):
         out["valu_insts_per_64_voxels"] = round(64.0 * c["SQ_INSTS_VALU"] / voxels, 1)
         out["lds_insts_per_64_voxels"] = round(64.0 * c.get("SQ_INSTS_LDS", 0) / voxels, 1)
         out["lds_array_cycles_per_64_voxels"] = round(64.0 * c.get("SQ_LDS_IDX_ACTIVE", 0) / voxels, 1)
+    # LDS instruction-issue model.  profiles/microbench/lds_cost.hip: on gfx950 one LDS instruction
+    # occupies the CU's LDS pipe for a time set by its kind and dwords per lane, NOT by the number
+    # of active lanes (cycles at 2.4 GHz, 16 waves per CU issuing back to back):
+    cost = dict(read_b32=3.1, read_b128=4.6, write_b32=4.35, write2_b32=6.4)
+    # k_describe per batch of 64 window voxels (static count of the main loop, sift3d_describe.hip):
+    mix = dict(rmw_read_b32=32, rmw_write_b32=32,           # 2 passes x 16 rounds, 2 voxels per round
+               record_read_b128=24,                         # 3 fields x 4 chunks x 2 passes
+               record_write2_b32=6, record_write_b32=2,     # 7 dwords per lane per pass
+               face_read_b128=4, octant_read_b32=1, queue_read_b32=1, queue_write_b32=2)
+    cyc = (mix["rmw_read_b32"] * cost["read_b32"] + mix["rmw_write_b32"] * cost["write_b32"] +
+           mix["record_read_b128"] * cost["read_b128"] + mix["record_write2_b32"] * cost["write2_b32"] +
+           mix["record_write_b32"] * cost["write_b32"] + mix["face_read_b128"] * cost["read_b128"] +
+           (mix["octant_read_b32"] + mix["queue_read_b32"]) * cost["read_b32"] +
+           mix["queue_write_b32"] * cost["write_b32"])
+    out["lds_issue_model"] = dict(cost_cycles_per_instruction=cost, instructions_per_64_voxels=mix,
+                                  lds_pipe_cycles_per_64_voxels=round(cyc, 1), clock_hz=2.4e9, cus=256,
+                                  seconds_if_lds_bound=round(voxels / 64.0 / 256.0 * cyc / 2.4e9, 5) if voxels else None,
+                                  note="the LDS pipe of a CU is the binding resource of k_describe: "
+                                       "frac = seconds_if_lds_bound / measured seconds")
     print(json.dumps(out, indent=1))
 
 

@@ -109,10 +109,16 @@ struct _sift3d_detector {
     int nfilt;
     /* device state */
     void *stream, *copy_stream;
+    void *oct_stream;      /* octaves >= 1 of the pyramid, beside the last levels of octave 0 */
+    void *side_stream;     /* ... and their levels that no later octave depends on */
+    void *ev_fork, *ev_join, *ev_join2;
+    void *ev_oct[32];      /* per octave: its downsampling source level is complete */
     int device;            /* HIP device of the streams / pyramids */
     void *ev[8];
     void *ev_chunk[8];
     float *d_im, *d_tmp_a, *d_tmp_b, *d_in;
+    float *d_tmp2_a, *d_tmp2_b;   /* scratch volumes of the octave stream (octave-1 size) */
+    float *d_tmp3_a, *d_tmp3_b;   /* ... and of the side stream */
     size_t in_cap;
     float **d_g, **d_d;    /* [num_octaves*ngl], [num_octaves*ndl] (DoG: only where stored) */
     unsigned char dog_free[64]; /* per octave: the last detect formed its DoG levels on the fly */
@@ -881,6 +887,11 @@ static void free_device_pyramid(sift3d_detector *d)
     sift3d_hip_free(d->d_im);
     sift3d_hip_free(d->d_tmp_a);
     sift3d_hip_free(d->d_tmp_b);
+    sift3d_hip_free(d->d_tmp2_a);
+    sift3d_hip_free(d->d_tmp2_b);
+    sift3d_hip_free(d->d_tmp3_a);
+    sift3d_hip_free(d->d_tmp3_b);
+    d->d_tmp2_a = d->d_tmp2_b = d->d_tmp3_a = d->d_tmp3_b = NULL;
     sift3d_hip_free(d->d_scalars);
     sift3d_hip_free(d->d_levels);
     sift3d_hip_free(d->d_work);
@@ -980,6 +991,15 @@ static int resize_detector(sift3d_detector *d)
     d->d_im = (float *)sift3d_hip_malloc(n0 * sizeof(float));
     d->d_tmp_a = (float *)sift3d_hip_malloc(n0 * sizeof(float));
     d->d_tmp_b = (float *)sift3d_hip_malloc(n0 * sizeof(float));
+    if (d->num_octaves > 1) {
+        const size_t n1 = (size_t)d->odims[1][0] * d->odims[1][1] * d->odims[1][2];
+        d->d_tmp2_a = (float *)sift3d_hip_malloc(n1 * sizeof(float));
+        d->d_tmp2_b = (float *)sift3d_hip_malloc(n1 * sizeof(float));
+        d->d_tmp3_a = (float *)sift3d_hip_malloc(n1 * sizeof(float));
+        d->d_tmp3_b = (float *)sift3d_hip_malloc(n1 * sizeof(float));
+        if (!d->d_tmp2_a || !d->d_tmp2_b || !d->d_tmp3_a || !d->d_tmp3_b)
+            return SIFT3D_FAILURE;
+    }
     d->d_scalars = (float *)sift3d_hip_malloc(sizeof(float) * (8 + (size_t)d->num_octaves * ndl));
     d->d_levels = (sift3d_hip_level *)sift3d_hip_malloc(sizeof(sift3d_hip_level) *
                                                         (size_t)d->num_octaves * ngl);
@@ -1100,6 +1120,13 @@ void sift3d_free_detector(sift3d_detector *d)
         sift3d_hip_event_destroy(d->ev[i]);
         sift3d_hip_event_destroy(d->ev_chunk[i]);
     }
+    sift3d_hip_event_destroy(d->ev_fork);
+    sift3d_hip_event_destroy(d->ev_join);
+    sift3d_hip_event_destroy(d->ev_join2);
+    for (i = 0; i < 32; i++)
+        sift3d_hip_event_destroy(d->ev_oct[i]);
+    sift3d_hip_stream_destroy(d->side_stream);
+    sift3d_hip_stream_destroy(d->oct_stream);
     sift3d_hip_stream_destroy(d->copy_stream);
     sift3d_hip_stream_destroy(d->stream);
     free(d);
@@ -1128,8 +1155,14 @@ static int ensure_device(sift3d_detector *d)
         return SIFT3D_FAILURE;
     }
     d->device = sift3d_hip_current_device();
-    if (!(d->stream = sift3d_hip_stream_create()) || !(d->copy_stream = sift3d_hip_stream_create()))
+    if (!(d->stream = sift3d_hip_stream_create()) || !(d->copy_stream = sift3d_hip_stream_create()) ||
+        !(d->oct_stream = sift3d_hip_stream_create_high()) ||
+        !(d->side_stream = sift3d_hip_stream_create_high()) || !(d->ev_fork = sift3d_hip_event_create()) ||
+        !(d->ev_join = sift3d_hip_event_create()) || !(d->ev_join2 = sift3d_hip_event_create()))
         return SIFT3D_FAILURE;
+    for (i = 0; i < 32; i++)
+        if (!(d->ev_oct[i] = sift3d_hip_event_create()))
+            return SIFT3D_FAILURE;
     for (i = 0; i < 8; i++)
         if (!(d->ev[i] = sift3d_hip_event_create()) || !(d->ev_chunk[i] = sift3d_hip_event_create()))
             return SIFT3D_FAILURE;
@@ -1186,34 +1219,35 @@ static int ensure_dog_octave(sift3d_detector *d, int o)
 /* apply_Sep_FIR_filter (imutil.c:1127-1206) on the device: x, y, z passes, the two
  * intermediates in scratch volumes, no permute copies */
 static int blur_level(sift3d_detector *d, const float *src, float *dst, const int *dims,
-                      const double *lu, const filter_t *f)
+                      const double *lu, const filter_t *f, void *stream, float *tmp_a, float *tmp_b)
 {
     const float *in = src;
     float *outs[3];
     int ax;
-    outs[0] = d->d_tmp_a;
-    outs[1] = d->d_tmp_b;
+    outs[0] = tmp_a;
+    outs[1] = tmp_b;
     outs[2] = dst;
+    (void)d;
     /* tap spacing 1 on y and z (octave 0 of a unit-spaced volume): x pass, then the fused
      * y+z kernel -- the y-pass result never goes to HBM */
     if ((float)(1.0 / lu[1]) == 1.0f && (float)(1.0 / lu[2]) == 1.0f) {
         sift3d_hip_fir_args a;
         int rc;
         memset(&a, 0, sizeof(a));
-        a.src = src; a.dst = d->d_tmp_a;
+        a.src = src; a.dst = tmp_a;
         a.nx = dims[0]; a.ny = dims[1]; a.nz = dims[2];
         a.axis = 0; a.width = f->width; a.taps = f->taps;
         a.unit_factor = (float)(1.0 / lu[0]);
         a.n_glob = dims[2]; a.z_lo = 0; a.z_hi = dims[2];
-        if (sift3d_hip_fir(&a, d->stream))
+        if (sift3d_hip_fir(&a, stream))
             return SIFT3D_FAILURE;
-        rc = sift3d_hip_fir_yz_u1(d->d_tmp_a, dst, dims[0], dims[1], dims[2], f->taps, f->width,
-                                  dims[2], 0, 0, dims[2], d->stream);
+        rc = sift3d_hip_fir_yz_u1(tmp_a, dst, dims[0], dims[1], dims[2], f->taps, f->width,
+                                  dims[2], 0, 0, dims[2], stream);
         if (rc == SIFT3D_SUCCESS)
             return SIFT3D_SUCCESS;
         if (rc != 1)
             return SIFT3D_FAILURE;
-        in = d->d_tmp_a;                 /* not covered: finish with separate y and z passes */
+        in = tmp_a;                 /* not covered: finish with separate y and z passes */
         for (ax = 1; ax < 3; ax++) {
             memset(&a, 0, sizeof(a));
             a.src = in; a.dst = outs[ax];
@@ -1221,7 +1255,7 @@ static int blur_level(sift3d_detector *d, const float *src, float *dst, const in
             a.axis = ax; a.width = f->width; a.taps = f->taps;
             a.unit_factor = (float)(1.0 / lu[ax]);
             a.n_glob = dims[2]; a.z_lo = 0; a.z_hi = dims[2];
-            if (sift3d_hip_fir(&a, d->stream))
+            if (sift3d_hip_fir(&a, stream))
                 return SIFT3D_FAILURE;
             in = outs[ax];
         }
@@ -1241,7 +1275,7 @@ static int blur_level(sift3d_detector *d, const float *src, float *dst, const in
         a.off = 0;
         a.z_lo = 0;
         a.z_hi = dims[2];
-        if (sift3d_hip_fir(&a, d->stream))
+        if (sift3d_hip_fir(&a, stream))
             return SIFT3D_FAILURE;
         in = outs[ax];
     }
@@ -1292,25 +1326,75 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     {
         double lu[3];
         level_units(d, 0, lu);
-        if (blur_level(d, d->d_im, d->d_g[0], d->odims[0], lu, &d->filt[0]))
+        if (blur_level(d, d->d_im, d->d_g[0], d->odims[0], lu, &d->filt[0], d->stream, d->d_tmp_a,
+                       d->d_tmp_b))
             return SIFT3D_FAILURE;
     }
-    for (o = 0; o < d->num_octaves; o++) {
-        double lu[3];
-        level_units(d, o, lu);
-        for (s = 1; s < d->ngl; s++)
-            if (blur_level(d, d->d_g[o * d->ngl + s - 1], d->d_g[o * d->ngl + s], d->odims[o], lu,
-                           &d->filt[s]))             /* gauss_octave[s], sift.c:689 */
-                return SIFT3D_FAILURE;
-        if (o != d->num_octaves - 1) {
-            /* level max(s_end - 2, first_level), sift.c:696-704 */
-            const int s_end = d->ngl - 2;
-            const int ds = s_end - 2 > -1 ? s_end - 2 : -1;
-            if (sift3d_hip_downsample2(d->d_g[o * d->ngl + ds + 1], d->odims[o][0], d->odims[o][1],
-                                       d->d_g[(o + 1) * d->ngl], d->odims[o + 1][0],
-                                       d->odims[o + 1][1], d->odims[o + 1][2], d->stream))
-                return SIFT3D_FAILURE;
+    {
+        /* Octave o + 1 starts from level max(s_end - 2, first_level) of octave o (sift.c:696-704);
+         * the levels after it belong to octave o alone.  So once that level of octave 0 exists, the
+         * smaller octaves -- short kernels that cannot fill the device -- are built on a second
+         * stream BESIDE the last levels of octave 0, their own last levels (which nothing waits
+         * for) on a third, and all are joined before the DoG stage. */
+        const int s_end = d->ngl - 2;
+        const int ds = s_end - 2 > -1 ? s_end - 2 : -1;
+        const int forked = d->num_octaves > 1 && d->num_octaves <= 32 && ds + 1 < d->ngl - 1;
+        for (o = 0; o < d->num_octaves; o++) {
+            double lu[3];
+            void *st = (o > 0 && forked) ? d->oct_stream : d->stream;
+            float *ta = (o > 0 && forked) ? d->d_tmp2_a : d->d_tmp_a;
+            float *tb = (o > 0 && forked) ? d->d_tmp2_b : d->d_tmp_b;
+            level_units(d, o, lu);
+            if (o == 0 && forked) {
+                /* octave 0 up to the source level, then the fork */
+                for (s = 1; s <= ds + 1; s++)
+                    if (blur_level(d, d->d_g[s - 1], d->d_g[s], d->odims[0], lu, &d->filt[s], d->stream,
+                                   d->d_tmp_a, d->d_tmp_b))
+                        return SIFT3D_FAILURE;
+                if (sift3d_hip_event_record(d->ev_fork, d->stream) ||
+                    sift3d_hip_stream_wait_event(d->oct_stream, d->ev_fork))
+                    return SIFT3D_FAILURE;
+                if (sift3d_hip_downsample2(d->d_g[ds + 1], d->odims[0][0], d->odims[0][1],
+                                           d->d_g[d->ngl], d->odims[1][0], d->odims[1][1], d->odims[1][2],
+                                           d->oct_stream))
+                    return SIFT3D_FAILURE;
+                for (; s < d->ngl; s++)
+                    if (blur_level(d, d->d_g[s - 1], d->d_g[s], d->odims[0], lu, &d->filt[s], d->stream,
+                                   d->d_tmp_a, d->d_tmp_b))
+                        return SIFT3D_FAILURE;
+                continue;
+            }
+            for (s = 1; s < d->ngl; s++) {
+                if (forked && s == ds + 2) {
+                    /* the rest of this octave leaves the critical chain */
+                    if (sift3d_hip_event_record(d->ev_oct[o], st) ||
+                        sift3d_hip_stream_wait_event(d->side_stream, d->ev_oct[o]))
+                        return SIFT3D_FAILURE;
+                    if (o != d->num_octaves - 1 &&
+                        sift3d_hip_downsample2(d->d_g[o * d->ngl + ds + 1], d->odims[o][0], d->odims[o][1],
+                                               d->d_g[(o + 1) * d->ngl], d->odims[o + 1][0],
+                                               d->odims[o + 1][1], d->odims[o + 1][2], st))
+                        return SIFT3D_FAILURE;
+                    st = d->side_stream;
+                    ta = d->d_tmp3_a;
+                    tb = d->d_tmp3_b;
+                }
+                if (blur_level(d, d->d_g[o * d->ngl + s - 1], d->d_g[o * d->ngl + s], d->odims[o], lu,
+                               &d->filt[s], st, ta, tb))         /* gauss_octave[s], sift.c:689 */
+                    return SIFT3D_FAILURE;
+            }
+            if (o != d->num_octaves - 1 && !forked) {
+                if (sift3d_hip_downsample2(d->d_g[o * d->ngl + ds + 1], d->odims[o][0], d->odims[o][1],
+                                           d->d_g[(o + 1) * d->ngl], d->odims[o + 1][0],
+                                           d->odims[o + 1][1], d->odims[o + 1][2], st))
+                    return SIFT3D_FAILURE;
+            }
         }
+        if (forked && (sift3d_hip_event_record(d->ev_join, d->oct_stream) ||
+                       sift3d_hip_stream_wait_event(d->stream, d->ev_join) ||
+                       sift3d_hip_event_record(d->ev_join2, d->side_stream) ||
+                       sift3d_hip_stream_wait_event(d->stream, d->ev_join2)))
+            return SIFT3D_FAILURE;
     }
     sift3d_hip_event_record(d->ev[2], d->stream);
 

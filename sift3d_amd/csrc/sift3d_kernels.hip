@@ -159,6 +159,21 @@ void *sift3d_hip_stream_create(void)
     return (void *)s;
 }
 
+// a stream whose kernels are dispatched ahead of those of ordinary streams (short, latency-bound
+// work that runs beside device-filling kernels)
+void *sift3d_hip_stream_create_high(void)
+{
+    hipStream_t s = nullptr;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi);
+    if (e != hipSuccess) {
+        fail("hipStreamCreateWithPriority", e, __FILE__, __LINE__);
+        return nullptr;
+    }
+    return (void *)s;
+}
+
 void sift3d_hip_stream_destroy(void *s)
 {
     if (s)
@@ -760,10 +775,12 @@ __global__ __launch_bounds__(256) void k_fir_sweep_dy(FirParams P, SweepGeom G, 
     }
 }
 
-template <int HW, int S>
+// RX outputs per lane: 8, or 4 for rows of at most 256 voxels (all 64 lanes busy from octave 1 of a
+// 512^3 volume on)
+template <int HW, int S, int RX>
 __global__ __launch_bounds__(256) void k_fir_x_dy(FirParams P, FirTaps T)
 {
-    constexpr int RX = 8, SEG = 64 * RX, HALO = 8, L = SEG + 2 * HALO;
+    constexpr int SEG = 64 * RX, HALO = 8, L = SEG + 2 * HALO;
     constexpr int R = (HW + (1 << S) - 1) >> S;
     static_assert(R + 1 <= HALO, "halo too small");
     __shared__ __attribute__((aligned(16))) float lds[4][L];
@@ -841,8 +858,9 @@ __global__ __launch_bounds__(256) void k_fir_x_dy(FirParams P, FirTaps T)
             if (xb + r < nx && xb + r >= P.uhw && xb + r <= nx - 2 - P.uhw)
                 d[xb + r] = o[r];
     } else if (vec_ok && xb + RX <= nx) {
-        st4(d + xb, make_float4(o[0], o[1], o[2], o[3]));
-        st4(d + xb + 4, make_float4(o[4], o[5], o[6], o[7]));
+#pragma unroll
+        for (int r = 0; r < RX; r += 4)
+            st4(d + xb + r, make_float4(o[r], o[r + 1], o[r + 2], o[r + 3]));
     } else {
 #pragma unroll
         for (int r = 0; r < RX; r++)
@@ -1729,11 +1747,15 @@ static void launch_fir_dy(const FirParams &P, const SweepGeom &G, const FirTaps 
 {
     if (P.axis == 0) {
         const int nrows = P.ny * (P.z_hi - P.z_lo);
-        const unsigned gx = (P.nx + 511) / 512;
+        const bool narrow = P.nx <= 256;
+        const unsigned gx = narrow ? (P.nx + 255) / 256 : (P.nx + 511) / 512;
         const size_t nedge = (size_t)nrows * (2 * P.uhw + 1);
         const unsigned eblocks = (unsigned)((nedge + (size_t)256 * gx - 1) / ((size_t)256 * gx));
         dim3 grid(gx, (nrows + 3) / 4 + eblocks);   // interior blocks, then boundary-column blocks
-        hipLaunchKernelGGL((k_fir_x_dy<HW, S>), grid, dim3(256), 0, st, P, T);
+        if (narrow)
+            hipLaunchKernelGGL((k_fir_x_dy<HW, S, 4>), grid, dim3(256), 0, st, P, T);
+        else
+            hipLaunchKernelGGL((k_fir_x_dy<HW, S, 8>), grid, dim3(256), 0, st, P, T);
     } else {
         const int nseg = (G.out_hi - G.out_lo + P.ts - 1) / P.ts;
         dim3 grid((G.ncols + 255) / 256, nseg);
