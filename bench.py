@@ -401,6 +401,15 @@ def main():
                            "hbm_GBs": round(tr / 1e9 / (dom["avg_ms"] * 1e-3), 1) if tr else None,
                            "algorithmic_bytes_per_launch": int(dom["algorithmic_GB"] * 1e9),
                            "avg_launch_ms": dom["avg_ms"], "pyramid": pyramid, "kernels": kb}
+        # avg_launch_ms is the kernel ALONE on the device (this leg's launches).  Inside the step
+        # the same launch -- the last blur of octave 0 -- shares the device with the streams that
+        # build octaves >= 1 (HIP events on its own stream, last step of the timed region); the
+        # rocprofv3 average in profiles/ is the mix of both kinds of launch.
+        yz_last = out.get("stage_s", {}).get("yz_last")
+        if yz_last:
+            out["roofline"]["avg_launch_ms_in_pipeline"] = round(1e3 * yz_last, 4)
+            out["roofline"]["in_pipeline_note"] = ("in the step this launch overlaps the octave >= 1 "
+                                                   "streams; avg_launch_ms is the kernel alone")
         dpath = os.path.join(ROOT, "profiles", "describe_model.json")
         if os.path.exists(dpath):
             try:

@@ -65,8 +65,10 @@ sift3d_amd_image_info(const sift3d_image *im, int *dims4, double *units3);
 /* Wall-clock seconds of the stages of the last detect/describe on `det`:
  * [0] upload+scale  [1] Gaussian pyramid  [2] DoG  [3] extrema  [4] orientation
  * [5] describe  [6] pyramid kernels only, device time from HIP events
- * [7] whole detect, device time  [8] whole describe, device time.  */
-#define SIFT3D_AMD_NUM_TIMINGS 9
+ * [7] whole detect, device time  [8] whole describe, device time
+ * [9] the LAST fused y+z FIR launch of octave 0 alone (HIP events on its stream; 0 when that blur did
+ *     not take the fused kernel) -- in the pipeline it shares the device with the octave streams.  */
+#define SIFT3D_AMD_NUM_TIMINGS 10
 SIFT3D_AMD_API const double *
 sift3d_amd_timings(const sift3d_detector *det);
 
@@ -355,6 +357,15 @@ sift3d_hip_extrema_gauss6(const float *const *d_g, const float *d_absmax, int nx
                           int z_lo, int z_hi, int tag0, double peak_thresh, sift3d_hip_cand *d_out,
                           uint32_t cap, uint32_t *d_count, void *d_work, size_t work_bytes,
                           void *stream);
+/* The same in two phases, so that the sweeps of different octaves can run side by side on different
+ * streams: phase 1 = the sweep (bit masks + block counts into d_work; touches nothing else), phase 2 =
+ * scan + emission appending at *d_count -- to be issued in octave order once the sweeps are done --,
+ * phase 0 = both.  d_work must keep its contents between the phases. */
+SIFT3D_AMD_API int
+sift3d_hip_extrema_gauss6_phase(const float *const *d_g, const float *d_absmax, int nx, int ny, int nz,
+                                int z_lo, int z_hi, int tag0, double peak_thresh, sift3d_hip_cand *d_out,
+                                uint32_t cap, uint32_t *d_count, void *d_work, size_t work_bytes,
+                                void *stream, int phase);
 
 /* Geometry of one Gaussian level, as the window kernels see it (a table of these
  * lives in device memory, indexed by the `tag`/`level` of a record). */

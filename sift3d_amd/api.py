@@ -19,7 +19,7 @@ from . import _native
 SIFT3D_SUCCESS = 0
 SIFT3D_FAILURE = -1
 SIFT3D_DOUBLE, SIFT3D_FLOAT, SIFT3D_INT = 0, 1, 2
-NUM_TIMINGS = 9
+NUM_TIMINGS = 10
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -348,7 +348,7 @@ class Detector:
     def timings(self):
         p = lib().sift3d_amd_timings(self.h)
         names = ("scale", "gauss", "dog", "extrema", "orient", "describe", "gauss_dev",
-                 "detect_wall", "describe_wall")
+                 "detect_wall", "describe_wall", "yz_last")
         return dict(zip(names, [p[i] for i in range(NUM_TIMINGS)]))
 
     def num_candidates(self):

@@ -112,6 +112,8 @@ struct _sift3d_detector {
     void *oct_stream;      /* octaves >= 1 of the pyramid, beside the last levels of octave 0 */
     void *side_stream;     /* ... and their levels that no later octave depends on */
     void *ev_fork, *ev_join, *ev_join2;
+    void *ev_yz[2];        /* around the last fused y+z launch of octave 0 */
+    int yz_timed;
     void *ev_oct[32];      /* per octave: its downsampling source level is complete */
     int device;            /* HIP device of the streams / pyramids */
     void *ev[8];
@@ -130,6 +132,8 @@ struct _sift3d_detector {
     int32_t *d_keep, *h_keep;
     void *d_work;
     size_t work_bytes;
+    void *d_work2;         /* extrema work areas of octaves >= 1 (kept between the two phases) */
+    size_t work2_off[64], work2_bytes;
     float *d_wlut;         /* per-level window-weight tables of the descriptor kernel */
     sift3d_hip_kp *d_kp, *h_kp;
     uint32_t kp_cap;
@@ -895,6 +899,9 @@ static void free_device_pyramid(sift3d_detector *d)
     sift3d_hip_free(d->d_scalars);
     sift3d_hip_free(d->d_levels);
     sift3d_hip_free(d->d_work);
+    sift3d_hip_free(d->d_work2);
+    d->d_work2 = NULL;
+    d->work2_bytes = 0;
     sift3d_hip_free(d->d_wlut);
     d->d_wlut = NULL;
     d->d_im = d->d_tmp_a = d->d_tmp_b = d->d_scalars = NULL;
@@ -984,6 +991,10 @@ static int resize_detector(sift3d_detector *d)
                 return SIFT3D_FAILURE;
         /* (DoG levels are allocated only where an octave needs them stored: ensure_dog_octave) */
         work = w > work ? w : work;
+        if (o >= 1 && o < 64) {
+            d->work2_off[o] = d->work2_bytes;
+            d->work2_bytes += (w + 255) & ~(size_t)255;
+        }
         for (s = 0; s < 3; s++)
             dims[s] /= 2;                            /* imutil.c:1545-1547 */
     }
@@ -1005,6 +1016,8 @@ static int resize_detector(sift3d_detector *d)
                                                         (size_t)d->num_octaves * ngl);
     d->d_work = sift3d_hip_malloc(work);
     d->work_bytes = work;
+    if (d->work2_bytes && !(d->d_work2 = sift3d_hip_malloc(d->work2_bytes)))
+        return SIFT3D_FAILURE;
     d->d_wlut = (float *)sift3d_hip_malloc(sizeof(float) *
                                            sift3d_hip_describe_wlut_floats(d->num_octaves * ngl));
     if (!d->d_wlut || !d->d_im || !d->d_tmp_a || !d->d_tmp_b || !d->d_scalars || !d->d_levels || !d->d_work)
@@ -1123,6 +1136,8 @@ void sift3d_free_detector(sift3d_detector *d)
     sift3d_hip_event_destroy(d->ev_fork);
     sift3d_hip_event_destroy(d->ev_join);
     sift3d_hip_event_destroy(d->ev_join2);
+    sift3d_hip_event_destroy(d->ev_yz[0]);
+    sift3d_hip_event_destroy(d->ev_yz[1]);
     for (i = 0; i < 32; i++)
         sift3d_hip_event_destroy(d->ev_oct[i]);
     sift3d_hip_stream_destroy(d->side_stream);
@@ -1158,7 +1173,8 @@ static int ensure_device(sift3d_detector *d)
     if (!(d->stream = sift3d_hip_stream_create()) || !(d->copy_stream = sift3d_hip_stream_create()) ||
         !(d->oct_stream = sift3d_hip_stream_create_high()) ||
         !(d->side_stream = sift3d_hip_stream_create_high()) || !(d->ev_fork = sift3d_hip_event_create()) ||
-        !(d->ev_join = sift3d_hip_event_create()) || !(d->ev_join2 = sift3d_hip_event_create()))
+        !(d->ev_join = sift3d_hip_event_create()) || !(d->ev_join2 = sift3d_hip_event_create()) ||
+        !(d->ev_yz[0] = sift3d_hip_event_create()) || !(d->ev_yz[1] = sift3d_hip_event_create()))
         return SIFT3D_FAILURE;
     for (i = 0; i < 32; i++)
         if (!(d->ev_oct[i] = sift3d_hip_event_create()))
@@ -1219,7 +1235,8 @@ static int ensure_dog_octave(sift3d_detector *d, int o)
 /* apply_Sep_FIR_filter (imutil.c:1127-1206) on the device: x, y, z passes, the two
  * intermediates in scratch volumes, no permute copies */
 static int blur_level(sift3d_detector *d, const float *src, float *dst, const int *dims,
-                      const double *lu, const filter_t *f, void *stream, float *tmp_a, float *tmp_b)
+                      const double *lu, const filter_t *f, void *stream, float *tmp_a, float *tmp_b,
+                      int time_yz)
 {
     const float *in = src;
     float *outs[3];
@@ -1227,7 +1244,6 @@ static int blur_level(sift3d_detector *d, const float *src, float *dst, const in
     outs[0] = tmp_a;
     outs[1] = tmp_b;
     outs[2] = dst;
-    (void)d;
     /* tap spacing 1 on y and z (octave 0 of a unit-spaced volume): x pass, then the fused
      * y+z kernel -- the y-pass result never goes to HBM */
     if ((float)(1.0 / lu[1]) == 1.0f && (float)(1.0 / lu[2]) == 1.0f) {
@@ -1241,10 +1257,17 @@ static int blur_level(sift3d_detector *d, const float *src, float *dst, const in
         a.n_glob = dims[2]; a.z_lo = 0; a.z_hi = dims[2];
         if (sift3d_hip_fir(&a, stream))
             return SIFT3D_FAILURE;
+        if (time_yz)
+            sift3d_hip_event_record(d->ev_yz[0], stream);
         rc = sift3d_hip_fir_yz_u1(tmp_a, dst, dims[0], dims[1], dims[2], f->taps, f->width,
                                   dims[2], 0, 0, dims[2], stream);
-        if (rc == SIFT3D_SUCCESS)
+        if (rc == SIFT3D_SUCCESS) {
+            if (time_yz) {
+                sift3d_hip_event_record(d->ev_yz[1], stream);
+                d->yz_timed = 1;
+            }
             return SIFT3D_SUCCESS;
+        }
         if (rc != 1)
             return SIFT3D_FAILURE;
         in = tmp_a;                 /* not covered: finish with separate y and z passes */
@@ -1298,7 +1321,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                              !d->num_octaves;
     const double t_start = now_s();
     uint32_t count = 0;
-    int o, s, i, j, attempt;
+    int o, s, i, j, attempt, side;
 
     /* set_im_SIFT3D, sift.c:629-659 */
     d->have_im = 1;
@@ -1322,12 +1345,13 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
         return SIFT3D_FAILURE;
 
     /* build_gpyr, sift.c:662-711 */
+    d->yz_timed = 0;
     sift3d_hip_event_record(d->ev[1], d->stream);
     {
         double lu[3];
         level_units(d, 0, lu);
         if (blur_level(d, d->d_im, d->d_g[0], d->odims[0], lu, &d->filt[0], d->stream, d->d_tmp_a,
-                       d->d_tmp_b))
+                       d->d_tmp_b, 0))
             return SIFT3D_FAILURE;
     }
     {
@@ -1349,7 +1373,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                 /* octave 0 up to the source level, then the fork */
                 for (s = 1; s <= ds + 1; s++)
                     if (blur_level(d, d->d_g[s - 1], d->d_g[s], d->odims[0], lu, &d->filt[s], d->stream,
-                                   d->d_tmp_a, d->d_tmp_b))
+                                   d->d_tmp_a, d->d_tmp_b, 0))
                         return SIFT3D_FAILURE;
                 if (sift3d_hip_event_record(d->ev_fork, d->stream) ||
                     sift3d_hip_stream_wait_event(d->oct_stream, d->ev_fork))
@@ -1360,7 +1384,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                     return SIFT3D_FAILURE;
                 for (; s < d->ngl; s++)
                     if (blur_level(d, d->d_g[s - 1], d->d_g[s], d->odims[0], lu, &d->filt[s], d->stream,
-                                   d->d_tmp_a, d->d_tmp_b))
+                                   d->d_tmp_a, d->d_tmp_b, s == d->ngl - 1))
                         return SIFT3D_FAILURE;
                 continue;
             }
@@ -1380,7 +1404,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                     tb = d->d_tmp3_b;
                 }
                 if (blur_level(d, d->d_g[o * d->ngl + s - 1], d->d_g[o * d->ngl + s], d->odims[o], lu,
-                               &d->filt[s], st, ta, tb))         /* gauss_octave[s], sift.c:689 */
+                               &d->filt[s], st, ta, tb, o == 0 && s == d->ngl - 1)) /* gauss_octave[s], sift.c:689 */
                     return SIFT3D_FAILURE;
             }
             if (o != d->num_octaves - 1 && !forked) {
@@ -1402,16 +1426,30 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
      * the maxima are computed here; the extrema sweep forms the differences itself and no DoG
      * level is stored.  Otherwise (cuboid neighbourhood, another level count, rows that are not
      * whole quads) the octave's DoG levels are stored as the reference does. */
+    /* Default configuration on every octave (and a second stream at hand): octave 0 on the main
+     * stream, the short launches of octaves >= 1 beside it -- in the DoG stage and again for the
+     * extrema sweeps, whose results are then emitted in octave order. */
+    side = !d->cuboid_extrema && d->ngl == 6 && d->num_octaves > 1 && d->num_octaves <= 64 && d->d_work2;
+    for (o = 0; o < d->num_octaves && side; o++)
+        side = (d->odims[o][0] & 3) == 0 && d->odims[o][2] >= 3;
+    if (side && (sift3d_hip_event_record(d->ev_fork, d->stream) ||
+                 sift3d_hip_stream_wait_event(d->oct_stream, d->ev_fork)))
+        return SIFT3D_FAILURE;
     for (o = 0; o < d->num_octaves; o++) {
         const size_t n = (size_t)d->odims[o][0] * d->odims[o][1] * d->odims[o][2];
         int rc = 1;
         d->dog_free[o] = 0;
         if (!d->cuboid_extrema && d->ngl == 6 && (d->odims[o][0] & 3) == 0 && d->odims[o][2] >= 3)
             rc = sift3d_hip_dogmax_stack((const float *const *)(d->d_g + o * d->ngl), d->ngl, n,
-                                         d->d_scalars + 8 + o * d->ndl, d->stream);
+                                         d->d_scalars + 8 + o * d->ndl,
+                                         side && o > 0 ? d->oct_stream : d->stream);
         if (rc == SIFT3D_SUCCESS) {
             d->dog_free[o] = 1;
             continue;
+        }
+        if (side) {
+            ERR("sift3d_amd: octave %d is not covered by the DoG-free path \n", o);
+            return SIFT3D_FAILURE;
         }
         if (rc != 1 || ensure_dog_octave(d, o))
             return SIFT3D_FAILURE;
@@ -1428,6 +1466,9 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                                            d->d_scalars + 8 + o * d->ndl + s, d->stream))
                 return SIFT3D_FAILURE;
     }
+    if (side && (sift3d_hip_event_record(d->ev_join, d->oct_stream) ||
+                 sift3d_hip_stream_wait_event(d->stream, d->ev_join)))
+        return SIFT3D_FAILURE;
     sift3d_hip_event_record(d->ev[3], d->stream);
 
     /* detect_extrema, sift.c:735-871 */
@@ -1440,7 +1481,32 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     for (attempt = 0; attempt < 2; attempt++) {
         if (sift3d_hip_memset(d->d_scalars + 1, 0, sizeof(uint32_t), d->stream))
             return SIFT3D_FAILURE;
-        for (o = 0; o < d->num_octaves; o++) {
+        if (side) {
+            /* the sweeps side by side, then scan + emission in octave order */
+            int phase;
+            if (sift3d_hip_event_record(d->ev_fork, d->stream) ||
+                sift3d_hip_stream_wait_event(d->oct_stream, d->ev_fork))
+                return SIFT3D_FAILURE;
+            for (phase = 1; phase <= 2; phase++) {
+                for (o = 0; o < d->num_octaves; o++) {
+                    void *wk = o ? (void *)((char *)d->d_work2 + d->work2_off[o]) : d->d_work;
+                    const size_t wb = o ? sift3d_hip_extrema_work_bytes(d->odims[o][0], d->odims[o][1],
+                                                                        d->odims[o][2], 3)
+                                        : d->work_bytes;
+                    if (sift3d_hip_extrema_gauss6_phase(
+                            (const float *const *)(d->d_g + o * d->ngl), d->d_scalars + 8 + o * d->ndl,
+                            d->odims[o][0], d->odims[o][1], d->odims[o][2], 1, d->odims[o][2] - 1,
+                            o * d->ngl + 1, d->peak_thresh, d->d_cand, d->cand_cap,
+                            (uint32_t *)(d->d_scalars + 1), wk, wb,
+                            phase == 1 && o > 0 ? d->oct_stream : d->stream, phase))
+                        return SIFT3D_FAILURE;   /* (coverage was established by the dogmax calls) */
+                }
+                if (phase == 1 && (sift3d_hip_event_record(d->ev_join, d->oct_stream) ||
+                                   sift3d_hip_stream_wait_event(d->stream, d->ev_join)))
+                    return SIFT3D_FAILURE;
+            }
+        }
+        for (o = 0; o < d->num_octaves && !side; o++) {
             sift3d_hip_extrema_level lv[8];
             const int nl = d->ndl - 2;
             if (nl > 8) {
@@ -1536,6 +1602,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     d->t[3] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[3], d->ev[4]);
     d->t[4] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[4], d->ev[5]);
     d->t[6] = d->t[1];
+    d->t[9] = d->yz_timed ? 1e-3 * sift3d_hip_event_elapsed_ms(d->ev_yz[0], d->ev_yz[1]) : 0.0;
     d->t[7] = now_s() - t_start;
     return SIFT3D_SUCCESS;
 }

@@ -2158,6 +2158,17 @@ int sift3d_hip_extrema_gauss6(const float *const *d_g, const float *d_absmax, in
                               uint32_t cap, uint32_t *d_count, void *d_work, size_t work_bytes,
                               void *stream)
 {
+    return sift3d_hip_extrema_gauss6_phase(d_g, d_absmax, nx, ny, nz, z_lo, z_hi, tag0, peak_thresh, d_out,
+                                           cap, d_count, d_work, work_bytes, stream, 0);
+}
+
+// phase 1: the sweep (masks + per-block counts in d_work; independent of every other octave);
+// phase 2: scan + emission, which appends to d_out at *d_count (so: in octave order); 0: both
+int sift3d_hip_extrema_gauss6_phase(const float *const *d_g, const float *d_absmax, int nx, int ny, int nz,
+                                    int z_lo, int z_hi, int tag0, double peak_thresh,
+                                    sift3d_hip_cand *d_out, uint32_t cap, uint32_t *d_count, void *d_work,
+                                    size_t work_bytes, void *stream, int phase)
+{
     hipStream_t st = (hipStream_t)stream;
     if ((size_t)nx * ny * nz >= (1ull << 32) || work_bytes < sift3d_hip_extrema_work_bytes(nx, ny, nz, 3)) {
         snprintf(g_err, sizeof(g_err), "sift3d_hip_extrema_gauss6: invalid arguments");
@@ -2185,8 +2196,9 @@ int sift3d_hip_extrema_gauss6(const float *const *d_g, const float *d_absmax, in
     S.wpr = E.wpr; S.nwords = E.nwords;
     S.masks32 = reinterpret_cast<uint32_t *>(masks);
     const int n_out = z_hi - z_lo;
-    HIPCHK(hipMemsetAsync(masks, 0, (size_t)3 * E.nwords * 8, st));
-    if (n_out > 0) {
+    if (phase != 2)
+        HIPCHK(hipMemsetAsync(masks, 0, (size_t)3 * E.nwords * 8, st));
+    if (n_out > 0 && phase != 2) {
         const long bxy = (long)((nx + 63) / 64) * ((ny + 15) / 16);
         long nseg = (2048 + bxy - 1) / bxy;
         const long cap_seg = n_out / 16 > 1 ? n_out / 16 : 1;
@@ -2195,7 +2207,12 @@ int sift3d_hip_extrema_gauss6(const float *const *d_g, const float *d_absmax, in
         dim3 grid((nx + 63) / 64, (ny + 15) / 16, (n_out + S.ts - 1) / S.ts);
         hipLaunchKernelGGL(k_extrema_sweep3<true>, grid, dim3(256), 0, st, S);
     }
-    hipLaunchKernelGGL(k_extrema_count, dim3(E.nblk, 3), dim3(256), 0, st, masks, E.nwords, E.nblk, blk);
+    if (phase != 2)
+        hipLaunchKernelGGL(k_extrema_count, dim3(E.nblk, 3), dim3(256), 0, st, masks, E.nwords, E.nblk, blk);
+    if (phase == 1) {
+        LAUNCH_CHECK();
+        return SIFT3D_SUCCESS;
+    }
     hipLaunchKernelGGL(k_extrema_scan, dim3(1), dim3(1024), 0, st, blk, E.nblk * 3u, d_count);
     ExLevels LV;
     memset(&LV, 0, sizeof(LV));
