@@ -357,21 +357,28 @@ int sift3d_amd_sharded_info(const sift3d_amd_sharded *S, int *num_octaves, int *
 }
 
 /* ---- exchanges ------------------------------------------------------------------------------ */
-/* Fill the h halo planes on both sides of the owned range of a level buffer (plane stride
- * `plane`, geometry of `L`) from the slab neighbours, on `stream`. */
-static int sh_halo(sift3d_amd_sharded *S, float *t, const sh_level *L, size_t plane, int h, void *stream)
+/* Fill halo planes on both sides of the owned range of a level buffer (plane stride `plane`,
+ * geometry of `L`) from the slab neighbours, on `stream`: the planes at distance (d0, h] from the
+ * slab boundary (d0 = 0: all h of them). */
+static int sh_halo_range(sift3d_amd_sharded *S, float *t, const sh_level *L, size_t plane, int d0, int h,
+                         void *stream)
 {
     const int a = L->z0 - L->off, b = L->z1 - L->off;
     const int lo = S->rank > 0 && L->z0 > 0, hi = S->rank < S->world - 1 && L->z1 < L->nz_glob;
-    if (S->world == 1 || h <= 0 || (!lo && !hi))
+    if (S->world == 1 || h <= d0 || (!lo && !hi))
         return SIFT3D_SUCCESS;
-    if (h > S->halo || h > b - a) {
+    if (h > S->halo || h > b - a || d0 < 0) {
         ERR("sift3d_amd_sharded: a %d-plane halo does not fit slabs of %d planes \n", h, b - a);
         return SIFT3D_FAILURE;
     }
-    return S->T.halo(S->T.ctx, lo ? t + (size_t)a * plane : NULL, lo ? t + (size_t)(a - h) * plane : NULL,
-                     hi ? t + (size_t)(b - h) * plane : NULL, hi ? t + (size_t)b * plane : NULL,
-                     (size_t)h * plane * sizeof(float), stream);
+    return S->T.halo(S->T.ctx, lo ? t + (size_t)(a + d0) * plane : NULL, lo ? t + (size_t)(a - h) * plane : NULL,
+                     hi ? t + (size_t)(b - h) * plane : NULL, hi ? t + (size_t)(b + d0) * plane : NULL,
+                     (size_t)(h - d0) * plane * sizeof(float), stream);
+}
+
+static int sh_halo(sift3d_amd_sharded *S, float *t, const sh_level *L, size_t plane, int h, void *stream)
+{
+    return sh_halo_range(S, t, L, plane, 0, h, stream);
 }
 
 static int sh_fir(sift3d_amd_sharded *S, const float *src, float *dst, int o, int nloc, int axis,
@@ -583,19 +590,12 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
     }
     sift3d_hip_event_record(S->ev1, S->stream);
 
-    /* window / DoG halos of the sharded octaves */
-    for (o = 0; o < S->o_shard; o++)
-        for (s = 0; s < SH_NGL; s++)
-            if (sh_halo(S, S->G[o][s].t, &S->G[o][s], sh_plane(S, o), S->win_reach[s], S->stream))
-                return SIFT3D_FAILURE;
-
-    /* dogmax (sift.c:821-826) of every octave on the owned planes (+ 1: harmless for a max), one
-     * all-reduce for all of them; no DoG level is stored */
+    /* dogmax (sift.c:821-826) of every octave on the owned planes (every plane is owned by some
+     * rank), one all-reduce for all of them; no DoG level is stored */
     for (o = 0; o < S->num_octaves; o++) {
         const sh_level *L = &S->G[o][0];
-        const int a = L->z0 - L->off, b = L->z1 - L->off;
-        const int lo = sh_sharded(S, o) ? (a - 1 > 0 ? a - 1 : 0) : 0;
-        const int hi = sh_sharded(S, o) ? (b + 1 < L->nloc ? b + 1 : L->nloc) : L->nloc;
+        const int lo = sh_sharded(S, o) ? L->z0 - L->off : 0;
+        const int hi = sh_sharded(S, o) ? L->z1 - L->off : L->nloc;
         const float *g[SH_NGL];
         for (s = 0; s < SH_NGL; s++)
             g[s] = S->G[o][s].t + (size_t)lo * sh_plane(S, o);
@@ -606,6 +606,29 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
     if (S->world > 1 &&
         S->T.allreduce_max(S->T.ctx, S->d_scalars + 8, SH_NDL * S->num_octaves, S->stream))
         return SIFT3D_FAILURE;
+
+    /* Halos of the sharded octaves.  The extrema sweep looks one plane past the slab; the windows
+     * of the orientation and descriptor kernels reach win_reach[s] planes.  The nearest plane is
+     * exchanged here; the rest -- the largest exchange of a step -- travels on the communication
+     * stream WHILE the extrema are found, and is awaited before the orientation kernel.  (No
+     * collective is issued on the compute stream in between: one communicator, one order.) */
+    for (o = 0; o < S->o_shard; o++)
+        for (s = 0; s < SH_NGL; s++)
+            if (sh_halo_range(S, S->G[o][s].t, &S->G[o][s], sh_plane(S, o), 0,
+                              S->win_reach[s] < 1 ? S->win_reach[s] : 1, S->stream))
+                return SIFT3D_FAILURE;
+    if (S->world > 1 && S->o_shard > 0) {
+        if (sift3d_hip_event_record(S->ev_x, S->stream) ||
+            sift3d_hip_stream_wait_event(S->comm_stream, S->ev_x))
+            return SIFT3D_FAILURE;
+        for (o = 0; o < S->o_shard; o++)
+            for (s = 0; s < SH_NGL; s++)
+                if (sh_halo_range(S, S->G[o][s].t, &S->G[o][s], sh_plane(S, o), 1, S->win_reach[s],
+                                  S->comm_stream))
+                    return SIFT3D_FAILURE;
+        if (sift3d_hip_event_record(S->ev_halo, S->comm_stream))
+            return SIFT3D_FAILURE;
+    }
 
     /* detect_extrema (sift.c:735-871) on the owned planes, assign_orientations (sift.c:1109-1167)
      * for the local candidates */
@@ -640,6 +663,8 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
         if (sh_ensure_cand(S, count + count / 4 + 1024))
             return SIFT3D_FAILURE;
     }
+    if (S->world > 1 && S->o_shard > 0 && sift3d_hip_stream_wait_event(S->stream, S->ev_halo))
+        return SIFT3D_FAILURE;                           /* the window halos have arrived */
     if (count) {
         if (sift3d_hip_orient(S->d_levels, S->d_cand, count, S->corner_thresh, S->d_R, S->d_keep,
                               S->stream) ||
