@@ -1262,6 +1262,185 @@ __global__ __launch_bounds__(256) void k_extrema_sweep3(ExSweep S)
     }
 }
 
+// ---- the same sweep straight from the SIX Gaussian levels, every sample loaded once ----------
+// k_extrema_sweep3<true> asks the memory system for ~26 KB per wave and plane (the y neighbours and
+// both Gaussian levels of every difference are loaded again by every thread that needs them): 5x
+// the bytes of the levels, and the L2 -> L1 path, not HBM, sets its time.  Here a thread loads
+// exactly its own quad of each Gaussian level once per plane (G1..G4 one plane ahead, G0 and G5 at
+// the centre plane), keeps what the next step needs in registers, and the workgroup trades the
+// centre-plane differences through an LDS tile (64 x 16 voxels + one halo row above and below,
+// loaded by 32 of the 256 threads) for the y neighbours.  One barrier per plane (the tile is
+// double-buffered).  Arithmetic, order of the tests and output are those of k_extrema_sweep3.
+template <int TXQ>
+__global__ __launch_bounds__(256) void k_extrema_sweep3g(ExSweep S)
+{
+    constexpr int TY = 256 / TXQ;          // tile: 4 * TXQ voxels along x, TY rows
+    __shared__ float4 tile[2][3][TY + 2][TXQ];
+    const int qx = threadIdx.x % TXQ, ty = threadIdx.x / TXQ;
+    const int q16 = qx & 15;               // position in the 16-lane row = the 64-voxel mask word
+    const int x = (blockIdx.x * TXQ + qx) * 4, y0 = blockIdx.y * TY, y = y0 + ty;
+    const int nx = S.nx, ny = S.ny;
+    const size_t ys = nx, zs = (size_t)nx * ny;
+    const bool col = x < nx && y < ny;                 // (nx % 4 == 0: whole quads)
+    const int yc = min(y, ny - 1), xc = min(x, nx - 4);
+    const size_t oc = (size_t)yc * ys + xc;
+    // halo rows of the tile (rows y0 - 1 and y0 + TY, clamped like the y neighbours of the
+    // reference loop's border voxels, which are never extrema): threads 0..31
+    const bool halo = threadIdx.x < 2 * TXQ;
+    const int hr = threadIdx.x / TXQ;                  // 0: row above, 1: row below (halo threads)
+    const int yh = hr == 0 ? max(y0 - 1, 0) : min(y0 + TY, ny - 1);
+    const size_t oh = (size_t)yh * ys + xc;
+    const int p0 = S.z_lo + blockIdx.z * S.ts, p1 = min(p0 + S.ts, S.z_hi);
+    if (p0 >= p1)
+        return;
+    float thr[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        thr[i] = (float)(S.peak_thresh * (double)(*S.absmax[i]));        // sift.c:829
+    bool okx[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+        okx[e] = col && y >= 1 && y <= ny - 2 && x + e >= 1 && x + e <= nx - 2;
+    auto sub4 = [](const float4 &a, const float4 &b) {
+        return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);   // im_subtract, imutil.c:719-739
+    };
+    // differences 1..3 at planes z-1 (m), z (c), z+1 (p); Gaussian levels 1 and 4 at plane z
+    float4 m[3], c[3], p[3], hc[3], g1c, g4c;
+    {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            a[k] = ld4(S.d[k + 1] + (size_t)(p0 - 1) * zs + oc);
+            b[k] = ld4(S.d[k + 1] + (size_t)p0 * zs + oc);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            m[i] = sub4(a[i], a[i + 1]);
+            c[i] = sub4(b[i], b[i + 1]);
+        }
+        g1c = b[0];
+        g4c = b[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            hc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (halo) {
+            float4 h[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                h[k] = ld4(S.d[k + 1] + (size_t)p0 * zs + oh);
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                hc[i] = sub4(h[i], h[i + 1]);
+        }
+    }
+    int buf = 0;
+#pragma unroll 1
+    for (int z = p0; z < p1; z++) {
+        const size_t zo = (size_t)z * zs;
+        // centre-plane differences into the tile (known since the previous step)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            tile[buf][i][ty + 1][qx] = c[i];
+            if (halo)
+                tile[buf][i][hr * (TY + 1)][qx] = hc[i];
+        }
+        // this step's loads: every Gaussian level once
+        float4 n[4], hn[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            n[k] = ld4(S.d[k + 1] + zo + zs + oc);
+        const float4 g0 = ld4(S.d[0] + zo + oc), g5 = ld4(S.d[5] + zo + oc);
+        if (halo) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                hn[k] = ld4(S.d[k + 1] + zo + zs + oh);
+        }
+        float lf[3], rt[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            // x neighbours of the quad's ends: adjacent lanes of the 16-lane row, or memory at
+            // the ends of the 64-voxel tile
+            if (TXQ == 64) {
+                // one row of 256 voxels per wave: the neighbours come from the adjacent lanes of
+                // the WAVE (DPP wave shift), memory only at the two ends of the row segment
+                lf[i] = __int_as_float(dpp_i<0x138>(__float_as_int(c[i].w)));   // wave_shr:1
+                rt[i] = __int_as_float(dpp_i<0x130>(__float_as_int(c[i].x)));   // wave_shl:1
+                if (qx == 0 && col && x > 0)
+                    lf[i] = S.d[i + 1][zo + oc - 1] - S.d[i + 2][zo + oc - 1];
+                if (qx == 63 && col && x + 4 < nx)
+                    rt[i] = S.d[i + 1][zo + oc + 4] - S.d[i + 2][zo + oc + 4];
+            } else {
+                lf[i] = __int_as_float(dpp_i<0x111>(__float_as_int(c[i].w)));   // row_shr:1
+                rt[i] = __int_as_float(dpp_i<0x101>(__float_as_int(c[i].x)));   // row_shl:1
+                if (q16 == 0 && col && x > 0)
+                    lf[i] = S.d[i + 1][zo + oc - 1] - S.d[i + 2][zo + oc - 1];
+                if (q16 == 15 && col && x + 4 < nx)
+                    rt[i] = S.d[i + 1][zo + oc + 4] - S.d[i + 2][zo + oc + 4];
+            }
+        }
+        __syncthreads();
+        float4 up[3], dn[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            up[i] = tile[buf][i][ty][qx];
+            dn[i] = tile[buf][i][ty + 2][qx];
+        }
+        buf ^= 1;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            p[i] = sub4(n[i], n[i + 1]);
+        const float4 d0c = sub4(g0, g1c), d4c = sub4(g4c, g5);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float4 pv = i == 0 ? d0c : c[i - 1], nv = i == 2 ? d4c : c[i + 1];
+            const float cv[4] = { c[i].x, c[i].y, c[i].z, c[i].w };
+            const float pr[4] = { pv.x, pv.y, pv.z, pv.w }, ne[4] = { nv.x, nv.y, nv.z, nv.w };
+            const float uu[4] = { up[i].x, up[i].y, up[i].z, up[i].w };
+            const float dd[4] = { dn[i].x, dn[i].y, dn[i].z, dn[i].w };
+            const float zm[4] = { m[i].x, m[i].y, m[i].z, m[i].w };
+            const float zp[4] = { p[i].x, p[i].y, p[i].z, p[i].w };
+            int nib = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float v = cv[e];
+                const float xm = e > 0 ? cv[e - 1] : lf[i], xp = e < 3 ? cv[e + 1] : rt[i];
+                // (no short circuit: in a wave some lane nearly always passes the threshold, so
+                // branches only cost)
+                const bool hit =
+                    okx[e] & ((v > thr[i]) | (v < -thr[i])) &                          // sift.c:842
+                    (((v > pr[e]) & (v > xp) & (v > xm) & (v > dd[e]) & (v > uu[e]) & (v > zm[e]) &
+                      (v > zp[e]) & (v > ne[e])) |
+                     ((v < pr[e]) & (v < xp) & (v < xm) & (v < dd[e]) & (v < uu[e]) & (v < zm[e]) &
+                      (v < zp[e]) & (v < ne[e])));                                     // sift.c:844-849
+                nib |= hit ? (1 << e) : 0;
+            }
+            // 64-bit word of the row: voxel 4*qx + e -> bit 4*qx + e; OR over the 16 lanes
+            int lo = q16 < 8 ? nib << (4 * q16) : 0, hi = q16 >= 8 ? nib << (4 * (q16 - 8)) : 0;
+            lo |= dpp_i<0x111>(lo); hi |= dpp_i<0x111>(hi);
+            lo |= dpp_i<0x112>(lo); hi |= dpp_i<0x112>(hi);
+            lo |= dpp_i<0x114>(lo); hi |= dpp_i<0x114>(hi);
+            lo |= dpp_i<0x118>(lo); hi |= dpp_i<0x118>(hi);
+            const int wcol = blockIdx.x * (TXQ / 16) + (qx >> 4);     // 64-voxel word of the row
+            if (q16 == 15 && wcol < S.wpr && y < ny) {
+                const size_t w = (size_t)i * S.nwords + ((size_t)z * ny + y) * S.wpr + wcol;
+                *reinterpret_cast<uint2 *>(S.masks32 + 2 * w) = make_uint2((unsigned)lo, (unsigned)hi);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            m[i] = c[i];
+            c[i] = p[i];
+        }
+        g1c = n[0];
+        g4c = n[3];
+        if (halo) {
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                hc[i] = sub4(hn[i], hn[i + 1]);
+        }
+    }
+}
+
 // candidates per block of EX_WPB mask words (what k_extrema_mask counts itself)
 __global__ __launch_bounds__(256) void k_extrema_count(const unsigned long long *__restrict__ masks,
                                                        uint32_t nwords, uint32_t nblk,
@@ -2199,13 +2378,22 @@ int sift3d_hip_extrema_gauss6_phase(const float *const *d_g, const float *d_absm
     if (phase != 2)
         HIPCHK(hipMemsetAsync(masks, 0, (size_t)3 * E.nwords * 8, st));
     if (n_out > 0 && phase != 2) {
-        const long bxy = (long)((nx + 63) / 64) * ((ny + 15) / 16);
+        // tile width: a whole wave per row where the rows are long enough (x neighbours then come
+        // from the wave itself; the two fetches at the ends of a row segment are the only reads
+        // outside the tile)
+        const int txq = nx >= 256 ? 64 : nx >= 128 ? 32 : 16, tyy = 256 / txq;
+        const long bxy = (long)((nx + 4 * txq - 1) / (4 * txq)) * ((ny + tyy - 1) / tyy);
         long nseg = (2048 + bxy - 1) / bxy;
         const long cap_seg = n_out / 16 > 1 ? n_out / 16 : 1;
         nseg = nseg < cap_seg ? nseg : cap_seg;
         S.ts = (int)((n_out + nseg - 1) / nseg);
-        dim3 grid((nx + 63) / 64, (ny + 15) / 16, (n_out + S.ts - 1) / S.ts);
-        hipLaunchKernelGGL(k_extrema_sweep3<true>, grid, dim3(256), 0, st, S);
+        dim3 grid((nx + 4 * txq - 1) / (4 * txq), (ny + tyy - 1) / tyy, (n_out + S.ts - 1) / S.ts);
+        if (txq == 32)
+            hipLaunchKernelGGL(k_extrema_sweep3g<32>, grid, dim3(256), 0, st, S);
+        else if (txq == 64)
+            hipLaunchKernelGGL(k_extrema_sweep3g<64>, grid, dim3(256), 0, st, S);
+        else
+            hipLaunchKernelGGL(k_extrema_sweep3g<16>, grid, dim3(256), 0, st, S);
     }
     if (phase != 2)
         hipLaunchKernelGGL(k_extrema_count, dim3(E.nblk, 3), dim3(256), 0, st, masks, E.nwords, E.nblk, blk);
