@@ -97,7 +97,7 @@ def kernel_microbench(torch, hip, n, reps=10):
         x_ms = sum(ev[3 * r].elapsed_time(ev[3 * r + 1]) for r in range(reps)) / reps
         yz_ms = sum(ev[3 * r + 1].elapsed_time(ev[3 * r + 2]) for r in range(reps)) / reps
         row("k_fir_x_u1<%d>" % hw, hw, 0, 8.0, x_ms, True)
-        row("k_fir_yz_u1<%d, 32>" % hw, hw, 12, 16.0, yz_ms, True)   # two 1-D passes = 16 B/voxel
+        row("k_fir_yz_u1<%d, 32, %d>" % (hw, 32 if n % 128 == 0 else 16), hw, 12, 16.0, yz_ms, True)   # two 1-D passes = 16 B/voxel
 
         def timed(fn):
             fn()
