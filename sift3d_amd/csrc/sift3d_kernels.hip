@@ -1144,8 +1144,8 @@ __global__ __launch_bounds__(256) void k_extrema_mask(ExLevels LV, ExGeom E,
 // 64-voxel mask words as k_extrema_mask, assembled with a DPP OR-reduction over the 16 lanes of
 // a row, so the scan and emit kernels (and with them the reference's scan order) are unchanged.
 struct ExSweep {
-    const float *d[6];        // DoG levels s-1 .. s+3 of the three keypoint levels -- or, for the
-                              // FROM_G instance, the SIX Gaussian levels they are differences of
+    const float *d[6];        // DoG levels s-1 .. s+3 of the three keypoint levels (k_extrema_sweep3) or
+                              // the SIX Gaussian levels they are differences of (k_extrema_sweep3g)
     const float *absmax[3];
     double peak_thresh;
     int nx, ny, nz;           // local dims
@@ -1160,20 +1160,11 @@ template <int CTRL> __device__ __forceinline__ int dpp_i(int v)
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);   // out-of-row lanes read 0
 }
 
-// FROM_G: level k of the sweep is Gaussian level k minus Gaussian level k + 1 (im_subtract,
-// imutil.c:719-739), formed when loaded -- the same float subtraction build_dog stores.
-template <bool FROM_G>
+// (Stored DoG levels; the default configuration has none and runs k_extrema_sweep3g below.)
 __global__ __launch_bounds__(256) void k_extrema_sweep3(ExSweep S)
 {
-    auto ldd4 = [&](int k, size_t o) -> float4 {
-        if (!FROM_G)
-            return ld4(S.d[k] + o);
-        const float4 a = ld4(S.d[k] + o), b = ld4(S.d[k + 1] + o);
-        return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
-    };
-    auto ldd1 = [&](int k, size_t o) -> float {
-        return FROM_G ? S.d[k][o] - S.d[k + 1][o] : S.d[k][o];
-    };
+    auto ldd4 = [&](int k, size_t o) -> float4 { return ld4(S.d[k] + o); };
+    auto ldd1 = [&](int k, size_t o) -> float { return S.d[k][o]; };
     constexpr int TY = 16;
     const int qx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int x = (blockIdx.x * 16 + qx) * 4, y = blockIdx.y * TY + ty;
@@ -1263,9 +1254,10 @@ __global__ __launch_bounds__(256) void k_extrema_sweep3(ExSweep S)
 }
 
 // ---- the same sweep straight from the SIX Gaussian levels, every sample loaded once ----------
-// k_extrema_sweep3<true> asks the memory system for ~26 KB per wave and plane (the y neighbours and
-// both Gaussian levels of every difference are loaded again by every thread that needs them): 5x
-// the bytes of the levels, and the L2 -> L1 path, not HBM, sets its time.  Here a thread loads
+// Forming the differences inside k_extrema_sweep3's loads would ask the memory system for ~26 KB
+// per wave and plane (the y neighbours and both Gaussian levels of every difference loaded again by
+// every thread that needs them): 5x the bytes of the levels, and the L2 -> L1 path, not HBM, then
+// sets the time (round 2 started that way).  Here a thread loads
 // exactly its own quad of each Gaussian level once per plane (G1..G4 one plane ahead, G0 and G5 at
 // the centre plane), keeps what the next step needs in registers, and the workgroup trades the
 // centre-plane differences through an LDS tile (64 x 16 voxels + one halo row above and below,
@@ -2281,7 +2273,7 @@ int sift3d_hip_extrema_mode(const sift3d_hip_extrema_level *levels, int nlevels,
                 nseg = nseg < cap_seg ? nseg : cap_seg;
                 S.ts = (int)((n_out + nseg - 1) / nseg);
                 dim3 grid((nx + 63) / 64, (ny + 15) / 16, (n_out + S.ts - 1) / S.ts);
-                hipLaunchKernelGGL(k_extrema_sweep3<false>, grid, dim3(256), 0, st, S);
+                hipLaunchKernelGGL(k_extrema_sweep3, grid, dim3(256), 0, st, S);
             }
             hipLaunchKernelGGL(k_extrema_count, dim3(E.nblk, 3), dim3(256), 0, st, masks, E.nwords,
                                E.nblk, blk);
