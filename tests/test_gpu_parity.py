@@ -165,7 +165,7 @@ def test_fir_slab_z(gpu, oracle_mod):
             np.testing.assert_array_equal(got[z0 - lo:z1 - lo], whole[z0:z1])
 
 
-@pytest.mark.parametrize("shape", [(40, 48, 64), (70, 33, 128), (24, 100, 20)])
+@pytest.mark.parametrize("shape", [(40, 48, 64), (70, 33, 128), (24, 100, 20), (36, 80, 256)])
 def test_fir_fused_yz_vs_oracle(gpu, oracle_mod, shape):
     """Fused y+z kernel == FIR_z(FIR_y(.)) of the oracle, whole volume and as Z-slabs (partial
     tiles in x and y, both global z faces, interior slab faces)."""
@@ -308,7 +308,8 @@ def test_detect_describe_golden(gpu, oracle_mod, name):
 
 
 @pytest.mark.parametrize("n,gen", [(96, "survey"), (160, "lattice"), ((100, 72, 90), "survey"),
-                                   ((130, 126, 122), "lattice")])   # last: no dimension a multiple of 4
+                                   ((130, 126, 122), "lattice"),    # no dimension a multiple of 4
+                                   ((320, 72, 64), "lattice")])     # rows of 1.25 256-voxel extrema tiles
 def test_detect_describe_vs_oracle(gpu, oracle_mod, n, gen):
     api, hip, torch = gpu
     vol = oracle_mod.synth_survey(n) if gen == "survey" else oracle_mod.synth_lattice(n, seed=3)
