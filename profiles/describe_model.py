@@ -29,7 +29,7 @@ def run(n=512):
 
 
 def count():
-    """Needs the diagnostic build (scratch/mkdiag.sh) in place of the library."""
+    """Needs the diagnostic build (make -C sift3d_amd/csrc DIAG=-DSIFT3D_AMD_DIAG, see the Makefile) in place of the library."""
     import ctypes as C
     from sift3d_amd import api
     L = api.lib()

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     // of the eight cells, the three barycentric weights, the three bin addresses.  Empty records
     // (zero weight, bin address 0) add 0 to a valid bin.
     // An LDS write costs by the instruction and the dwords per lane, whatever the number of
-    // active lanes (scratch/mb/lds_cost.hip), so all 64 lanes write in both passes: the 14 fields
+    // active lanes (profiles/microbench/lds_cost.hip), so all 64 lanes write in both passes: the 14 fields
     // are traded between the half-waves (v_permlane32_swap) so that lane l holds, for voxel l & 31
     // of each half-batch, fields 0..6 (l < 32) or 7..13 (l >= 32): rp[pass][i].
     float rp[2][7] = { { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f } };
