@@ -66,6 +66,9 @@ struct sift3d_amd_sharded {
     filter_t filt[SH_NGL];
     /* device state */
     void *stream, *comm_stream, *ev_x, *ev_halo, *ev0, *ev1;
+    void *oct_stream, *ev_fork, *ev_join;   /* extrema sweeps of octaves >= 1 beside octave 0's */
+    void *d_work2;                          /* their work areas, kept until the ordered emission */
+    size_t work2_off[SH_MAX_OCT], work2_sz[SH_MAX_OCT], work2_bytes;
     sh_level G[SH_MAX_OCT][SH_NGL];
     sh_level tmp_a, tmp_b, im;       /* scratch levels of octave 0 size (re-described per octave) */
     float *d_tmp_a, *d_tmp_b, *d_im, *d_raw, *d_stage;
@@ -153,6 +156,8 @@ void sift3d_amd_sharded_free(sift3d_amd_sharded *S)
         sift3d_hip_stream_sync(S->stream);
     if (S->comm_stream)
         sift3d_hip_stream_sync(S->comm_stream);
+    if (S->oct_stream)
+        sift3d_hip_stream_sync(S->oct_stream);
     for (o = 0; o < SH_MAX_OCT; o++)
         for (s = 0; s < SH_NGL; s++)
             sh_free_level(&S->G[o][s]);
@@ -160,13 +165,16 @@ void sift3d_amd_sharded_free(sift3d_amd_sharded *S)
         free(S->filt[s].taps);
     sift3d_hip_free(S->d_tmp_a); sift3d_hip_free(S->d_tmp_b); sift3d_hip_free(S->d_im);
     sift3d_hip_free(S->d_raw); sift3d_hip_free(S->d_stage); sift3d_hip_free(S->d_scalars);
-    sift3d_hip_free(S->d_levels); sift3d_hip_free(S->d_work); sift3d_hip_free(S->d_cand);
+    sift3d_hip_free(S->d_levels); sift3d_hip_free(S->d_work); sift3d_hip_free(S->d_work2);
+    sift3d_hip_free(S->d_cand);
     sift3d_hip_free(S->d_R); sift3d_hip_free(S->d_keep); sift3d_hip_free(S->d_xchg);
     sift3d_hip_free(S->d_kp); sift3d_hip_free(S->d_wlut);
     sift3d_hip_host_free(S->h_cand); sift3d_hip_host_free(S->h_R); sift3d_hip_host_free(S->h_keep);
     sift3d_hip_host_free(S->h_xchg); sift3d_hip_host_free(S->h_kp);
     sift3d_hip_event_destroy(S->ev_x); sift3d_hip_event_destroy(S->ev_halo);
     sift3d_hip_event_destroy(S->ev0); sift3d_hip_event_destroy(S->ev1);
+    sift3d_hip_event_destroy(S->ev_fork); sift3d_hip_event_destroy(S->ev_join);
+    sift3d_hip_stream_destroy(S->oct_stream);
     sift3d_hip_stream_destroy(S->comm_stream);
     sift3d_hip_stream_destroy(S->stream);
     free(S);
@@ -247,7 +255,9 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
         }
     if (!(S->stream = sift3d_hip_stream_create()) || !(S->comm_stream = sift3d_hip_stream_create()) ||
         !(S->ev_x = sift3d_hip_event_create()) || !(S->ev_halo = sift3d_hip_event_create()) ||
-        !(S->ev0 = sift3d_hip_event_create()) || !(S->ev1 = sift3d_hip_event_create()) || upload_mesh())
+        !(S->ev0 = sift3d_hip_event_create()) || !(S->ev1 = sift3d_hip_event_create()) ||
+        !(S->oct_stream = sift3d_hip_stream_create_high()) || !(S->ev_fork = sift3d_hip_event_create()) ||
+        !(S->ev_join = sift3d_hip_event_create()) || upload_mesh())
         goto fail;
     /* levels */
     for (o = 0; o < S->num_octaves; o++) {
@@ -257,6 +267,11 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
         const int hi = sh_sharded(S, o) ? (z1 + S->halo < nzo ? z1 + S->halo : nzo) : nzo;
         const size_t w = sift3d_hip_extrema_work_bytes(S->dims[o][0], S->dims[o][1], hi - off, SH_K);
         work = w > work ? w : work;
+        if (o >= 1) {
+            S->work2_off[o] = S->work2_bytes;
+            S->work2_sz[o] = w;
+            S->work2_bytes += (w + 255) & ~(size_t)255;
+        }
         for (s = 0; s < SH_NGL; s++) {
             sh_level *L = &S->G[o][s];
             L->off = off; L->nloc = hi - off; L->z0 = z0; L->z1 = z1; L->nz_glob = nzo;
@@ -295,6 +310,8 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
     S->d_levels = (sift3d_hip_level *)sift3d_hip_malloc(sizeof(sift3d_hip_level) * SH_MAX_OCT * SH_NGL);
     S->d_work = sift3d_hip_malloc(work);
     S->work_bytes = work;
+    if (S->work2_bytes && !(S->d_work2 = sift3d_hip_malloc(S->work2_bytes)))
+        goto fail;
     S->d_wlut = (float *)sift3d_hip_malloc(sizeof(float) *
                                            sift3d_hip_describe_wlut_floats(S->num_octaves * SH_NGL));
     if (!S->d_wlut || !S->d_tmp_a || !S->d_tmp_b || !S->d_im || !S->d_raw || !S->d_stage || !S->d_scalars ||
@@ -637,23 +654,41 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
     for (attempt = 0; attempt < 2; attempt++) {
         if (sift3d_hip_memset(S->d_scalars + 1, 0, sizeof(uint32_t), S->stream))
             return SIFT3D_FAILURE;
-        for (o = 0; o < S->num_octaves; o++) {
-            const sh_level *L = &S->G[o][0];
-            const int nzo = S->dims[o][2];
-            const int zl = (L->z0 > 1 ? L->z0 : 1) - L->off;
-            int zh = (L->z1 < nzo - 1 ? L->z1 : nzo - 1) - L->off;
-            const float *g[SH_NGL];
-            if (zh < zl)
-                zh = zl;
-            for (s = 0; s < SH_NGL; s++)
-                g[s] = S->G[o][s].t;
-            if (L->nloc < 3 || zh <= zl)
-                continue;                                /* no interior plane on this rank */
-            if (sift3d_hip_extrema_gauss6(g, S->d_scalars + 8 + SH_NDL * o, S->dims[o][0], S->dims[o][1],
-                                          L->nloc, zl, zh, o * SH_NGL + 1, S->peak_thresh, S->d_cand,
-                                          S->cand_cap, (uint32_t *)(S->d_scalars + 1), S->d_work,
-                                          S->work_bytes, S->stream) != SIFT3D_SUCCESS)
+        /* the sweeps of octaves >= 1 (short launches) beside octave 0's on a second stream, then scan
+         * + emission in octave order (sift3d_hip_extrema_gauss6_phase) */
+        {
+            const int side = S->num_octaves > 1 && S->d_work2 != NULL;
+            int phase;
+            if (side && (sift3d_hip_event_record(S->ev_fork, S->stream) ||
+                         sift3d_hip_stream_wait_event(S->oct_stream, S->ev_fork)))
                 return SIFT3D_FAILURE;
+            for (phase = side ? 1 : 0; phase <= (side ? 2 : 0); phase++) {
+                for (o = 0; o < S->num_octaves; o++) {
+                    const sh_level *L = &S->G[o][0];
+                    const int nzo = S->dims[o][2];
+                    const int zl = (L->z0 > 1 ? L->z0 : 1) - L->off;
+                    int zh = (L->z1 < nzo - 1 ? L->z1 : nzo - 1) - L->off;
+                    const float *g[SH_NGL];
+                    void *wk = side && o > 0 ? (void *)((char *)S->d_work2 + S->work2_off[o]) : S->d_work;
+                    const size_t wb = side && o > 0 ? S->work2_sz[o] : S->work_bytes;
+                    if (zh < zl)
+                        zh = zl;
+                    for (s = 0; s < SH_NGL; s++)
+                        g[s] = S->G[o][s].t;
+                    if (L->nloc < 3 || zh <= zl)
+                        continue;                            /* no interior plane on this rank */
+                    if (sift3d_hip_extrema_gauss6_phase(g, S->d_scalars + 8 + SH_NDL * o, S->dims[o][0],
+                                                        S->dims[o][1], L->nloc, zl, zh, o * SH_NGL + 1,
+                                                        S->peak_thresh, S->d_cand, S->cand_cap,
+                                                        (uint32_t *)(S->d_scalars + 1), wk, wb,
+                                                        phase == 1 && o > 0 ? S->oct_stream : S->stream,
+                                                        phase) != SIFT3D_SUCCESS)
+                        return SIFT3D_FAILURE;
+                }
+                if (phase == 1 && (sift3d_hip_event_record(S->ev_join, S->oct_stream) ||
+                                   sift3d_hip_stream_wait_event(S->stream, S->ev_join)))
+                    return SIFT3D_FAILURE;
+            }
         }
         if (sift3d_hip_memcpy_d2h(&count, S->d_scalars + 1, sizeof(count), S->stream) ||
             sift3d_hip_stream_sync(S->stream))
