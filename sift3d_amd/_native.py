@@ -19,7 +19,7 @@ def build(force=False):
     """Compile the HIP kernels for gfx950 and the C host code (in-tree, via make)."""
     if force:
         subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
-    subprocess.check_call(["make", "-s", "-C", CSRC])
+    subprocess.check_call(["make", "-s", "-j4", "-C", CSRC])      # four device translation units
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("build did not produce %s" % LIB_PATH)
     return LIB_PATH
