@@ -1352,23 +1352,14 @@ __global__ __launch_bounds__(256) void k_extrema_sweep3g(ExSweep S)
         for (int i = 0; i < 3; i++) {
             // x neighbours of the quad's ends: adjacent lanes of the 16-lane row, or memory at
             // the ends of the 64-voxel tile
-            if (TXQ == 64) {
-                // one row of 256 voxels per wave: the neighbours come from the adjacent lanes of
-                // the WAVE (DPP wave shift), memory only at the two ends of the row segment
-                lf[i] = __int_as_float(dpp_i<0x138>(__float_as_int(c[i].w)));   // wave_shr:1
-                rt[i] = __int_as_float(dpp_i<0x130>(__float_as_int(c[i].x)));   // wave_shl:1
-                if (qx == 0 && col && x > 0)
-                    lf[i] = S.d[i + 1][zo + oc - 1] - S.d[i + 2][zo + oc - 1];
-                if (qx == 63 && col && x + 4 < nx)
-                    rt[i] = S.d[i + 1][zo + oc + 4] - S.d[i + 2][zo + oc + 4];
-            } else {
-                lf[i] = __int_as_float(dpp_i<0x111>(__float_as_int(c[i].w)));   // row_shr:1
-                rt[i] = __int_as_float(dpp_i<0x101>(__float_as_int(c[i].x)));   // row_shl:1
-                if (q16 == 0 && col && x > 0)
-                    lf[i] = S.d[i + 1][zo + oc - 1] - S.d[i + 2][zo + oc - 1];
-                if (q16 == 15 && col && x + 4 < nx)
-                    rt[i] = S.d[i + 1][zo + oc + 4] - S.d[i + 2][zo + oc + 4];
-            }
+            // the neighbours come from the adjacent lanes of the WAVE (DPP wave shift; a wave holds
+            // 64 / TXQ whole row segments), memory only at the two ends of a row segment
+            lf[i] = __int_as_float(dpp_i<0x138>(__float_as_int(c[i].w)));   // wave_shr:1
+            rt[i] = __int_as_float(dpp_i<0x130>(__float_as_int(c[i].x)));   // wave_shl:1
+            if (qx == 0)
+                lf[i] = col && x > 0 ? S.d[i + 1][zo + oc - 1] - S.d[i + 2][zo + oc - 1] : 0.0f;
+            if (qx == TXQ - 1)
+                rt[i] = col && x + 4 < nx ? S.d[i + 1][zo + oc + 4] - S.d[i + 2][zo + oc + 4] : 0.0f;
         }
         __syncthreads();
         float4 up[3], dn[3];
@@ -2370,9 +2361,9 @@ int sift3d_hip_extrema_gauss6_phase(const float *const *d_g, const float *d_absm
     if (phase != 2)
         HIPCHK(hipMemsetAsync(masks, 0, (size_t)3 * E.nwords * 8, st));
     if (n_out > 0 && phase != 2) {
-        // tile width: a whole wave per row where the rows are long enough (x neighbours then come
-        // from the wave itself; the two fetches at the ends of a row segment are the only reads
-        // outside the tile)
+        // tile width: a whole wave per row where the rows are long enough -- 1 KB row segments
+        // (measured at 512^3: 1.6 ms for the stage against 1.9 / 2.0 with 512 / 256-byte segments,
+        // although the 4-row tiles re-read more halo rows)
         const int txq = nx >= 256 ? 64 : nx >= 128 ? 32 : 16, tyy = 256 / txq;
         const long bxy = (long)((nx + 4 * txq - 1) / (4 * txq)) * ((ny + tyy - 1) / tyy);
         long nseg = (2048 + bxy - 1) / bxy;
