@@ -35,6 +35,17 @@ from oracle import sift3d_oracle as so  # noqa: E402
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
+def desc_projection(h):
+    """Every histogram row projected on 8 seeded random unit vectors (N x 8 float64).  Pins ALL
+    rows of a large fixture -- which bin the mass of a row sits in, not only its sum
+    (reference binning: sift3d/sift.c:1355-1373, 1514-1526) -- in 64 bytes per row.  The
+    columns have unit 2-norm, so an elementwise relative error e of the row moves a projection
+    by at most e * |row|_2."""
+    P = np.random.default_rng(20240768).standard_normal((768, 8))
+    P /= np.linalg.norm(P, axis=0, keepdims=True)
+    return np.ascontiguousarray(h, np.float64) @ P
+
+
 def digest(a):
     """sha1 over float32 values with -0.0 folded into +0.0."""
     a = np.ascontiguousarray(a, np.float32) + np.float32(0.0)
@@ -161,6 +172,7 @@ def end_to_end(name, vol, units=(1, 1, 1), full_levels_below=17, desc_stride=1, 
         d["desc_xyzsd"] = x
         d["desc_rowsum"] = h.astype(np.float64).sum(axis=1)
         d["desc_rowsumsq"] = (h.astype(np.float64) ** 2).sum(axis=1)
+        d["desc_proj"] = desc_projection(h)
         # sort_by_strength(limit): resulting order expressed as (o,s,x,y,z,strength) rows
         for lim in (0, 10):
             q = refprobe.Probe(**params)
@@ -216,6 +228,8 @@ def end_to_end_digest(name, vol, stride=97, input_spec=None):
     dig["desc_hist"] = digest(np.ascontiguousarray(h))
     d["desc_hist_s"] = h[::stride]
     d["desc_rowsum"] = h.astype(np.float64).sum(axis=1).astype(np.float32)
+    d["desc_proj"] = desc_projection(h)
+    d["desc_rownorm"] = np.sqrt((h.astype(np.float64) ** 2).sum(axis=1))
     d["digests"] = np.array(json.dumps(dig))
     if input_spec:
         d["input_spec"] = np.array(json.dumps(input_spec))

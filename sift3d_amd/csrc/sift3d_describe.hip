@@ -214,6 +214,11 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
             wtab = tab + WL_HEAD;                    // wave-uniform
     }
 
+    typedef const float __attribute__((address_space(1))) *gfloat_p;
+    // (without a table the batch still issues its -- then unused -- weight load: any valid address)
+    const gfloat_p wsrc = wtab ? (gfloat_p)wtab : (gfloat_p) reinterpret_cast<const float *>(levels);
+    const int wmask = wtab ? -1 : 0;
+
     const float sigma = (float)(K.sd * 7.071067812);                  // sift.c:1453
     const float rad = (float)(2.0 * (double)sigma);                   // sift.c:1454
     const float half_w = (float)((double)rad / 1.4142135623730951);   // / sqrt(2), sift.c:1455
@@ -244,6 +249,9 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
 
     uint32_t qhead = 0, qtail = 0; // wave-uniform
     bool pend = false;             // registers pv/ppk hold the batch starting at qhead
+#ifdef SIFT3D_AMD_DIAG
+    unsigned diag_voxels = 0;      // window voxels of this keypoint (one atomic per wave at the end)
+#endif
 
     // Window voxel -> (window test, spatial bins).  Same float expressions in the scan and
     // in the batch, so both see identical values.
@@ -271,7 +279,6 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     int ppk = 0;
     // level samples are read through a global-address-space pointer (the pointer comes out of a
     // table in memory, which would otherwise make these flat loads); nx*ny < 2^31
-    typedef const float __attribute__((address_space(1))) *gfloat_p;
     const gfloat_p gdata = (gfloat_p)L.data;
     const uint32_t ys32 = (uint32_t)L.nx, zs32 = (uint32_t)L.nx * (uint32_t)L.ny;
     // Sample requests of a batch, branch-free: lanes beyond cnt keep their previous (valid) voxel
@@ -332,101 +339,126 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
             rrow[i * RROW] = rp[pass][i];
         wave_sync();
     };
-    auto commit_rounds = [&]() {
-        if (DESC_ABLATE(1)) return;
-        const int hb = half * 16;
-        int4 mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb]);
-        float4 mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb]);
-        float4 bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb]);
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int mb[4] = { mb4.x, mb4.y, mb4.z, mb4.w };
-            const float mv[4] = { mw4.x, mw4.y, mw4.z, mw4.w }, bv[4] = { bw4.x, bw4.y, bw4.z, bw4.w };
-            if (c < 3) {
-                mb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb + 4 * c + 4]);
-                mw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb + 4 * c + 4]);
-                bw4 = *reinterpret_cast<const float4 *>(&bw[pj][hb + 4 * c + 4]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                float *bin = reinterpret_cast<float *>(reinterpret_cast<char *>(hist) + (mb[u] + coff4));
-                const float val = mv[u] * bv[u];                               // sift.c:1371-1373
-                *bin = *bin + val;
-            }
-        }
-    };
+    // The commit chain, interleaved BY HAND with the per-voxel arithmetic.  A round is
+    //     address, ds_read_b32 (bin) | ... | s_waitcnt, v_add_f32, ds_write_b32
+    // and the next round's read can only be issued after this round's write, so a round costs one
+    // LDS round trip (>= 64 cycles, more when the pipe is busy) during which the wave has nothing
+    // of the chain to do.  Left to itself the scheduler puts the whole chain in one piece and all
+    // other arithmetic of the basic block before and after it (every round then exposes its full
+    // latency, and only the other waves of the SIMD can fill it).  Here every round carries a
+    // SLICE of independent work -- a dozen VALU instructions of phase A of this batch, or of the
+    // sample requests of the next -- between the bin read and the wait for it; scheduling
+    // barriers keep the slices where they are put.  Records of four rounds are read with three
+    // 16-byte loads, one chunk ahead.
+#define SB() __builtin_amdgcn_sched_barrier(0)
+// a value is computed in the slice that names it here (not sunk to its first use in a later one)
+#define KEEP(v) asm volatile("" ::"v"(v))
+#define COMMIT_BEGIN()                                                                        \
+    int4 cb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb]);                                   \
+    float4 cw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb]);                               \
+    float4 cx4 = *reinterpret_cast<const float4 *>(&bw[pj][hb]);                               \
+    int4 nb4 = cb4;                                                                           \
+    float4 nw4 = cw4, nx4 = cx4;
+#define ROUND(u, ...)                                                                         \
+    {                                                                                         \
+        if (((u) & 3) == 0 && (u) + 4 < 16) {                                                 \
+            nb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb + (u) + 4]);                      \
+            nw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb + (u) + 4]);                    \
+            nx4 = *reinterpret_cast<const float4 *>(&bw[pj][hb + (u) + 4]);                    \
+        }                                                                                     \
+        const int mb_[4] = { cb4.x, cb4.y, cb4.z, cb4.w };                                    \
+        const float mv_[4] = { cw4.x, cw4.y, cw4.z, cw4.w }, bv_[4] = { cx4.x, cx4.y, cx4.z, cx4.w }; \
+        float *bin_ = reinterpret_cast<float *>(reinterpret_cast<char *>(hist) + (mb_[(u) & 3] + coff4)); \
+        const float val_ = mv_[(u) & 3] * bv_[(u) & 3];                   /* sift.c:1371-1373 */ \
+        float old_ = 0.0f;                                                                    \
+        if (!DESC_ABLATE(1))                                                                  \
+            old_ = *bin_;                                                                     \
+        SB();                                                                                 \
+        { __VA_ARGS__ }                                                                       \
+        SB();                                                                                 \
+        if (!DESC_ABLATE(1))                                                                  \
+            *bin_ = old_ + val_;                                                              \
+        if (((u) & 3) == 3) {                                                                 \
+            cb4 = nb4;                                                                        \
+            cw4 = nw4;                                                                        \
+            cx4 = nx4;                                                                        \
+        }                                                                                     \
+        SB();                                                                                 \
+    }
     // One batch: phase A of `cnt` (<= 64) voxels whose samples were fetched one batch ago (cv,
-    // pk), overlapped with the two commit passes of the previous batch (records in rp)
-    // and with the sample requests of the next one (ncnt voxels from queue position nstart;
-    // ncnt may be 0); then this batch's records take the previous one's place.
+    // pk), woven into the two commit passes of the previous batch (records in rp), as are the
+    // sample requests of the next batch (ncnt voxels from queue position nstart; ncnt may be 0);
+    // then this batch's records take the previous one's place.
+    // One commit pass: the records of half a batch (voxels 32 * pass .. 32 * pass + 31) go to
+    // LDS, field-major, then round u adds voxel u of them (half-wave 0) and voxel 16 + u
+    // (half-wave 1), each into its half-wave's own histogram.  The 24 lanes of a voxel own 24
+    // distinct bins (8 cells x 3 face vertices), so the voxel's adds are ONE plain LDS
+    // read-modify-write; the DS operations of a wave execute in issue order, so round u + 1
+    // sees round u's sums.  (Reading round u + 1's bins before round u's sums are written is
+    // not an option: a bin of round u + 1 is usually a bin that ANOTHER lane writes in round u.)
     auto batch = [&](int cnt, const float *cv, int pk, uint32_t nstart, int ncnt) {
 #ifdef SIFT3D_AMD_DIAG
-        if (lane == 0)
-            atomicAdd(&g_desc_voxels, (unsigned long long)cnt);
+        diag_voxels += (unsigned)cnt;
 #endif
-        prefetch_loads(nstart, ncnt);
-        if (DESC_ABLATE(2)) { prefetch_weight(); return; }
-        commit_write(0);
-        // ---- basic block 1: commit rounds of voxels 0..31  ||  window, gradient, face
-        commit_rounds();
+        if (DESC_ABLATE(2)) { prefetch(nstart, ncnt); return; }
+        const int hb = half * 16;
         // (lanes beyond cnt compute on stale -- finite -- values and are discarded below)
-        const int x = B.xs + (pk & 1023), y = B.ys + ((pk >> 10) & 1023), z = B.zs + (pk >> 20);
-        float sq, vbx, vby, vbz;
-        window(x, y, z, sq, vbx, vby, vbz);
-        // IM_GET_GRAD_ISO (sift.c:140-145, immacros.h:105-111)
-        float gx = 0.5f * (cv[0] - cv[1]), gy = 0.5f * (cv[2] - cv[3]), gz = 0.5f * (cv[4] - cv[5]);
-        gx *= iux;
-        gy *= iuy;
-        gz *= iuz;
-        const float w = cv[6];                                 // sift.c:1498, see prefetch_weight
-        gx = gx * w; gy = gy * w; gz = gz * w;
-        const float rx = R[0] * gx + R[3] * gy + R[6] * gz;    // sift.c:1502
-        const float ry = R[1] * gx + R[4] * gy + R[7] * gz;
-        const float rz = R[2] * gx + R[5] * gy + R[8] * gz;
-        const float m2 = rx * rx + ry * ry + rz * rz;
-        const bool live = lane < cnt && !(m2 < 1.1920928955078125e-06f);   // sift.c:1264
-        // icos_hist_bin (sift.c:1268-1286): the first face in table order whose barycentrics
-        // are >= -eps wins.  A face other than the one the ray really crosses can only pass
-        // if the ray misses it by ~eps, i.e. if the ray is within ~eps of an edge of its own
-        // face.  So: guess the face, evaluate it with cart2bary's arithmetic, and accept it
-        // when it passes with all barycentrics > 2e-5 (then every other face fails by a wide
-        // margin and the first match is unique); anything else -- ~1e-4 of the voxels --
-        // takes the reference's scan over all 20 faces.
+        int x, y, z;
+        float dx, dy, dz, kx, ky, kz, vbx, vby, vbz, gx, gy, gz, rx, ry, rz, m2;
+        float t1, t2, t3, px, py, pz, det, di, kk;
+        float4 A0, A1, A2, A3;
+        int f0;
+        bool live = false, found = false;
         int fidx = 0;
         float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-        const int f0 = soct[icos_guess(rx, ry, rz)];
-        bool found = face_eval(reinterpret_cast<const float4 *>(sface + f0 * FACE_STRIDE), rx, ry, rz, b0, b1,
-                               b2, fidx) &&
-                     fminf(b0, fminf(b1, b2)) > 2e-5f;
-        commit_write(1);
-        // ---- basic block 2: commit rounds of voxels 32..63  ||  cell weights, next batch's
-        // Gaussian weights
-        commit_rounds();
-        prefetch_weight();
-        // trilinear cell weights (sift.c:1318-1320, 1361-1363): weight = wx * wy * wz,
-        // value = mag * weight * bary.  A corner beyond the last cell is skipped by the
-        // reference (sift.c:1349-1352).  The commit below is free of predication -- all 24 lanes
-        // of a voxel always read-modify-write -- so the 2x2x2 block of cells is shifted to stay
-        // inside the grid instead: on an axis where the base cell is the last one (index 3) the
-        // block covers cells {2, 3}, cell 3 keeps its weight 1 - f and cell 2 gets weight 0.
-        // The 24 bins stay distinct and valid; adding mag * 0 * bary = +-0 changes nothing.
-        const float mag = sqrtf(m2);                           // sift.c:1331
-        const float fx = vbx - floorf(vbx);
-        const float fy = vby - floorf(vby);
-        const float fz = vbz - floorf(vbz);
-        const int ix = (int)vbx, iy = (int)vby, iz = (int)vbz;
-        const bool lx = ix >= 3, ly = iy >= 3, lz = iz >= 3;
-        const float ax[2] = { lx ? 0.0f : 1.0f - fx, lx ? 1.0f - fx : fx },
-                    ay[2] = { ly ? 0.0f : 1.0f - fy, ly ? 1.0f - fy : fy },
-                    az[2] = { lz ? 0.0f : 1.0f - fz, lz ? 1.0f - fz : fz };
-        float mwv[8];
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const float wt = ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1];
-            mwv[c] = mag * wt;
+        // ================= pass 0: rounds of voxels 0..31  ||  window, gradient, face
+        commit_write(0);
+        {
+            COMMIT_BEGIN();
+            ROUND(0, x = B.xs + (pk & 1023); y = B.ys + ((pk >> 10) & 1023); z = B.zs + (pk >> 20);
+                     dx = ((float)x - K.cx) * L.ux; KEEP(dx);)             // sift.c:102-104
+            ROUND(1, dy = ((float)y - K.cy) * L.uy; dz = ((float)z - K.cz) * L.uz; KEEP(dy); KEEP(dz);
+                     // IM_GET_GRAD_ISO (sift.c:140-145, immacros.h:105-111)
+                     gx = 0.5f * (cv[0] - cv[1]); gy = 0.5f * (cv[2] - cv[3]); gz = 0.5f * (cv[4] - cv[5]);)
+            ROUND(2, gx *= iux; gy *= iuy; gz *= iuz;
+                     gx = gx * cv[6]; gy = gy * cv[6]; gz = gz * cv[6];)   // sift.c:1498, see prefetch_weight
+            // vkp = Rt * vim (immacros.h:328-340)
+            ROUND(3, kx = R[0] * dx + R[3] * dy + R[6] * dz; ky = R[1] * dx + R[4] * dy + R[7] * dz; KEEP(kx); KEEP(ky);)
+            ROUND(4, kz = R[2] * dx + R[5] * dy + R[8] * dz;
+                     vbx = (kx + half_w) * bin_f; vby = (ky + half_w) * bin_f; vbz = (kz + half_w) * bin_f; // sift.c:1483-1485
+                     KEEP(vbx); KEEP(vby); KEEP(vbz);)
+            ROUND(5, rx = R[0] * gx + R[3] * gy + R[6] * gz; ry = R[1] * gx + R[4] * gy + R[7] * gz;) // sift.c:1502
+            ROUND(6, rz = R[2] * gx + R[5] * gy + R[8] * gz; m2 = rx * rx + ry * ry + rz * rz;
+                     live = lane < cnt && !(m2 < 1.1920928955078125e-06f);)   // sift.c:1264
+            // icos_hist_bin (sift.c:1268-1286): the first face in table order whose barycentrics
+            // are >= -eps wins.  A face other than the one the ray really crosses can only pass
+            // if the ray misses it by ~eps, i.e. if the ray is within ~eps of an edge of its own
+            // face.  So: guess the face (icos_guess), evaluate it with cart2bary's arithmetic
+            // (face_eval), and accept it when it passes with all barycentrics > 2e-5 (then every
+            // other face fails by a wide margin and the first match is unique); anything else --
+            // ~1e-4 of the voxels -- takes the reference's scan over all 20 faces.
+            ROUND(7, const float g = 1.6180339887f, g2 = 2.6180339887f;
+                     const float ax_ = fabsf(rx), ay_ = fabsf(ry), az_ = fabsf(rz);
+                     t1 = ax_ + g2 * ay_ - g * az_; t2 = ay_ + g2 * az_ - g * ax_; t3 = az_ + g2 * ax_ - g * ay_;)
+            // (a value read from LDS in one slice is used in a LATER one, so that no slice waits)
+            ROUND(8, const int n1 = t1 < 0.0f, n2 = t2 < 0.0f, n3 = t3 < 0.0f;
+                     const int cls = n1 + (1 - n1) * (2 * n2 + (1 - n2) * 3 * n3);
+                     f0 = soct[cls * 8 + (int)(rx < 0.0f) + 2 * (int)(ry < 0.0f) + 4 * (int)(rz < 0.0f)];)
+            ROUND(9, const float4 *fr = reinterpret_cast<const float4 *>(sface + f0 * FACE_STRIDE);
+                     A0 = fr[0]; A1 = fr[1]; A2 = fr[2]; A3 = fr[3];)
+            // cart2bary (sift.c:276-297): e1 = A0.xyz, e2 = (A0.w, A1.x, A1.y), t = (A1.z, A1.w, A2.x),
+            // q = (A2.y, A2.z, A2.w), e2.q = A3.x, bin offsets = A3.y
+            ROUND(10, px = ry * A1.y - rz * A1.x; py = rz * A0.w - rx * A1.y; pz = rx * A1.x - ry * A0.w;) // p = g x e2
+            ROUND(11, det = A0.x * px + A0.y * py + A0.z * pz; di = 1.0f / det;)
+            ROUND(12, b1 = di * (A1.z * px + A1.w * py + A2.x * pz);)
+            ROUND(13, b2 = di * (rx * A2.y + ry * A2.z + rz * A2.w); b0 = 1.0f - b1 - b2;)
+            ROUND(14, kk = A3.x * di; fidx = __float_as_int(A3.y);
+                      found = !(fabsf(det) < 1.1920928955078125e-06f) &&            // sift.c:282
+                              !(b0 < -1.1920928955078125e-06f || b1 < -1.1920928955078125e-06f ||
+                                b2 < -1.1920928955078125e-06f || kk < 0) &&          // sift.c:1277-1279
+                              fminf(b0, fminf(b1, b2)) > 2e-5f;)
+            ROUND(15, )
         }
-        // (stale lanes may hold any coordinates: keep their cell inside the grid as well)
-        const int cell4 = 4 * (min(max(ix, 0), 2) + 4 * min(max(iy, 0), 2) + 16 * min(max(iz, 0), 2));
         if (__builtin_expect(__ballot(live && !found) != 0ull, 0)) {
             bool open = live && !found;
 #pragma unroll 1
@@ -444,27 +476,78 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
                     break;
             }
         }
-        // this batch's records (voxels without a contribution: zero weights, bin address 0)
-        const bool ok = live && found;
-        float fld[14];
-#pragma unroll
-        for (int c = 0; c < 8; c++)
-            fld[c] = ok ? mwv[c] : 0.0f;
-        fld[8] = ok ? b0 : 0.0f; fld[9] = ok ? b1 : 0.0f; fld[10] = ok ? b2 : 0.0f;   // (0 * NaN would be NaN)
-        // byte addresses of the bins (base cell, face vertex j) -- the vertices addressed
-        // through the UNSWAPPED idx[] of the face (quirk Q1)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            fld[11 + j] = __int_as_float(ok ? 4 * ((fidx >> (10 * j)) & 1023) + cell4 : 0);
-        // swap(a, b): first result = a of lanes 0..31 | b of lanes 0..31, second = a of lanes
-        // 32..63 | b of lanes 32..63
-#pragma unroll
-        for (int i = 0; i < 7; i++) {
-            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(fld[i]), __float_as_uint(fld[7 + i]),
-                                                            false, false);
-            rp[0][i] = __uint_as_float(r[0]);
-            rp[1][i] = __uint_as_float(r[1]);
+        // ================= pass 1: rounds of voxels 32..63  ||  the next batch's sample requests,
+        // cell weights, this batch's records
+        commit_write(1);
+        {
+            COMMIT_BEGIN();
+            int nx_, ny_, nzl_, qv_;
+            gfloat_p np_;
+            float mag, fx, fy, fz;
+            int ix, iy, iz, cell4;
+            float ax[2], ay[2], az[2], fld[14];
+            // Sample requests of the next batch, branch-free: lanes beyond ncnt keep their previous
+            // (valid) voxel and simply fetch it again
+            ROUND(0, qv_ = queue[(nstart + lane) & (DQ - 1)];)
+            ROUND(1, ppk = lane < ncnt ? qv_ : ppk;
+                     nx_ = B.xs + (ppk & 1023); ny_ = B.ys + ((ppk >> 10) & 1023); nzl_ = B.zs + (ppk >> 20) - L.z_off;
+                     np_ = gdata + ((uint64_t)zs32 * (uint32_t)nzl_ + (uint32_t)(nx_ + (int)ys32 * ny_));)
+            ROUND(2, pv[0] = np_[1]; pv[1] = *(np_ - 1); pv[2] = np_[ys32]; pv[3] = *(np_ - ys32);)
+            // the Gaussian weight is a seventh (L2-resident) load, in flight with the samples (without a
+            // table the load is a dummy and prefetch_weight() computes the weight)
+            ROUND(3, pv[4] = np_[zs32]; pv[5] = *(np_ - zs32);
+                     const int i = nx_ - icx; const int j = ny_ - icy; const int l = B.zs + (ppk >> 20) - icz;
+                     pv[6] = wsrc[(i * i + j * j + l * l) & wmask];)
+            // trilinear cell weights (sift.c:1318-1320, 1361-1363): weight = wx * wy * wz,
+            // value = mag * weight * bary.  A corner beyond the last cell is skipped by the
+            // reference (sift.c:1349-1352).  The commit is free of predication -- all 24 lanes
+            // of a voxel always read-modify-write -- so the 2x2x2 block of cells is shifted to stay
+            // inside the grid instead: on an axis where the base cell is the last one (index 3) the
+            // block covers cells {2, 3}, cell 3 keeps its weight 1 - f and cell 2 gets weight 0.
+            // The 24 bins stay distinct and valid; adding mag * 0 * bary = +-0 changes nothing.
+            // Voxels without a contribution: magnitude 0 (all eight weights become +-0; the stale
+            // values behind them are finite), barycentrics 0 (0 * NaN would be NaN); their bin
+            // addresses stay valid ones.
+            ROUND(4, mag = sqrtf(m2); mag = live && found ? mag : 0.0f;)               // sift.c:1331
+            ROUND(5, fx = vbx - floorf(vbx); fy = vby - floorf(vby); fz = vbz - floorf(vbz);
+                     ix = (int)vbx; iy = (int)vby; iz = (int)vbz;)
+            ROUND(6, const bool lx = ix >= 3; const bool ly = iy >= 3; const bool lz = iz >= 3;
+                     ax[0] = lx ? 0.0f : 1.0f - fx; ax[1] = lx ? 1.0f - fx : fx;
+                     ay[0] = ly ? 0.0f : 1.0f - fy; ay[1] = ly ? 1.0f - fy : fy;
+                     az[0] = lz ? 0.0f : 1.0f - fz; az[1] = lz ? 1.0f - fz : fz;)
+            ROUND(7, _Pragma("unroll") for (int c = 0; c < 4; c++)
+                         fld[c] = mag * (ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1]);)
+            ROUND(8, _Pragma("unroll") for (int c = 4; c < 8; c++)
+                         fld[c] = mag * (ax[(c >> 2) & 1] * ay[(c >> 1) & 1] * az[c & 1]);)
+            // (stale lanes may hold any coordinates: keep their cell inside the grid as well)
+            ROUND(9, cell4 = 4 * (min(max(ix, 0), 2) + 4 * min(max(iy, 0), 2) + 16 * min(max(iz, 0), 2));
+                     const bool ok = live && found;
+                     fld[8] = ok ? b0 : 0.0f; fld[9] = ok ? b1 : 0.0f; fld[10] = ok ? b2 : 0.0f;)
+            // byte addresses of the bins (base cell, face vertex j) -- the vertices addressed
+            // through the UNSWAPPED idx[] of the face (quirk Q1)
+            ROUND(10, _Pragma("unroll") for (int j = 0; j < 3; j++)
+                          fld[11 + j] = __int_as_float(4 * ((fidx >> (10 * j)) & 1023) + cell4);)
+            // swap(a, b): first result = a of lanes 0..31 | b of lanes 0..31, second = a of lanes
+            // 32..63 | b of lanes 32..63
+            ROUND(11, _Pragma("unroll") for (int i = 0; i < 4; i++) {
+                          const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(fld[i]), __float_as_uint(fld[7 + i]), false, false);
+                          rp[0][i] = __uint_as_float(r[0]); rp[1][i] = __uint_as_float(r[1]); })
+            ROUND(12, _Pragma("unroll") for (int i = 4; i < 7; i++) {
+                          const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(fld[i]), __float_as_uint(fld[7 + i]), false, false);
+                          rp[0][i] = __uint_as_float(r[0]); rp[1][i] = __uint_as_float(r[1]); })
+            ROUND(13, )
+            ROUND(14, )
+            ROUND(15, )
         }
+        prefetch_weight();
+    };
+    // the commit passes of the last batch (nothing left to weave in)
+    auto commit_tail = [&](int pass) {
+        const int hb = half * 16;
+        commit_write(pass);
+        COMMIT_BEGIN();
+        ROUND(0, ) ROUND(1, ) ROUND(2, ) ROUND(3, ) ROUND(4, ) ROUND(5, ) ROUND(6, ) ROUND(7, )
+        ROUND(8, ) ROUND(9, ) ROUND(10, ) ROUND(11, ) ROUND(12, ) ROUND(13, ) ROUND(14, ) ROUND(15, )
     };
 
     // The reference scans the whole bounding box of the sphere (sift.c:96-108).  Every voxel
@@ -554,11 +637,13 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
             rest = 0;
         }
     }
+#ifdef SIFT3D_AMD_DIAG
+    if (lane == 0)
+        atomicAdd(&g_desc_voxels, (unsigned long long)diag_voxels);
+#endif
     // the last batch
-    commit_write(0);
-    commit_rounds();
-    commit_write(1);
-    commit_rounds();
+    commit_tail(0);
+    commit_tail(1);
     wave_sync();
     // The two half-wave histograms are merged in a fixed order, then normalize_desc -> clamp ->
     // normalize_desc (sift.c:1402-1429, 1514-1526).  The reference sums the 768 squares in

@@ -6,7 +6,7 @@
 // stage: PARITY UNPINNED.  What is built is the textbook form of what upstream describes --
 // for every descriptor of set A the nearest and second nearest descriptor of set B under the L2
 // distance, accepted by Lowe's ratio test -- validated by recovering a known transform
-// (tests/test_gpu_match.py).
+// (tests/test_register.py).
 //
 // This is the one dense contraction of the project: |a - b|^2 = |a|^2 + |b|^2 - 2 a.b, an
 // (nA x 768) x (768 x nB) matrix product, done on the matrix cores with

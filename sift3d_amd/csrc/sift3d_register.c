@@ -11,7 +11,7 @@
  *   fitting    12-parameter affine y = A [x; 1] by least squares inside RANSAC: random minimal
  *              samples of 4 matches, inliers by residual, best consensus refit on its inliers.
  * Validated by recovering a known transform between two synthetic volumes
- * (tests/test_gpu_match.py). */
+ * (tests/test_register.py). */
 
 static int reg_upload(const sift3d_descriptor_store *d, float **dev)
 {
@@ -43,13 +43,13 @@ int sift3d_amd_nn_match(const sift3d_descriptor_store *a, const sift3d_descripto
     if (!na || !nb)
         return SIFT3D_SUCCESS;
     {
-        const int nmax = na > nb ? na : nb;
-        work = (float *)sift3d_hip_malloc(sizeof(float) * sift3d_hip_nn2_work_floats(na, nb));
+        /* one scratch buffer serves both directions: size it for the larger of the two */
+        const size_t wf = sift3d_hip_nn2_work_floats(na, nb), wb = sift3d_hip_nn2_work_floats(nb, na);
+        work = (float *)sift3d_hip_malloc(sizeof(float) * (wf > wb ? wf : wb));
         d1 = (float *)sift3d_hip_malloc(sizeof(float) * 2 * (size_t)(na + nb));
         dj = (int *)sift3d_hip_malloc(sizeof(int) * (size_t)(na + nb));
         h = (float *)malloc(sizeof(float) * 2 * (size_t)(na + nb));
         hj = (int *)malloc(sizeof(int) * (size_t)(na + nb));
-        (void)nmax;
     }
     if (!work || !d1 || !dj || !h || !hj || reg_upload(a, &da) || reg_upload(b, &db))
         goto done;

@@ -370,6 +370,8 @@ def test_g5_256_golden(gpu, oracle_mod):
     idx = g["desc_idx"]
     assert util.rel_err(m[idx, 3:], g["desc_hist"]) <= RTOL
     np.testing.assert_allclose(m[:, 3:].astype(np.float64).sum(1), g["desc_rowsum"], rtol=1e-5)
+    # ALL 3 481 rows, bin placement included (sift.c:1355-1373): 8 random projections per row
+    util.assert_desc_projection(m[:, 3:], g["desc_proj"])
 
 
 def test_reuse_and_errors(gpu, oracle_mod):
@@ -436,6 +438,9 @@ def test_g5_512_golden(gpu, oracle_mod):
     m = desc.to_mat_rm()
     assert util.rel_err(m[idx, 3:], g["desc_hist_s"]) <= RTOL
     np.testing.assert_allclose(m[:, 3:].astype(np.float64).sum(1), g["desc_rowsum"], rtol=1e-5)
+    # ALL 42 501 rows, bin placement included (sift.c:1355-1373, 1514-1526)
+    worst = util.assert_desc_projection(m[:, 3:], g["desc_proj"])
+    print("g5_512: worst projection error over all rows: %.3g of the row norm" % worst)
     # R is accumulated in the reference's order: the digest of all 42 501 matrices must match
     assert exact_R, "R differs from the reference at 512^3"
     print("g5_512: max elementwise relative descriptor error on the sampled rows: %.3g"

@@ -151,6 +151,7 @@ def test_end_to_end(oracle_mod, name):
     assert util.rel_err(d["hist"][idx], g["desc_hist"]) <= 1e-5
     np.testing.assert_array_equal(d["hist"][idx], g["desc_hist"])
     np.testing.assert_allclose(d["hist"].astype(np.float64).sum(1), g["desc_rowsum"], rtol=1e-6)
+    assert util.assert_desc_projection(d["hist"], g["desc_proj"], rtol=1e-12) < 1e-12   # every row
     for lim in (0, 10):
         o2, _ = _run(oracle_mod, g)
         o2.sort_by_strength(lim)

@@ -62,6 +62,43 @@ def test_nn2_against_numpy():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("na,nb", [(3000, 6000), (100, 40000), (700, 300)])
+def test_nn_match_store_api_against_numpy(na, nb):
+    """sift3d_amd_nn_match through the descriptor stores with very different store sizes (the
+    scratch buffer serves both directions): mutual nearest neighbours under the ratio test,
+    against float64 numpy.  A third of b's rows are noisy copies of rows of a, so that real
+    matches exist."""
+    from sift3d_amd import api
+    rng = np.random.default_rng(5 + na)
+    a = np.abs(rng.standard_normal((na, 768))).astype(np.float32)
+    b = np.abs(rng.standard_normal((nb, 768))).astype(np.float32)
+    src = rng.integers(0, na, nb // 3)
+    b[: nb // 3] = a[src] + 0.05 * rng.standard_normal((nb // 3, 768)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    da, db = api.DescriptorStore(), api.DescriptorStore()
+    assert da.set(np.zeros((na, 4)), a) == 0 and db.set(np.zeros((nb, 4)), b) == 0
+    thr = 0.8
+    got = api.nn_match(da, db, thr)
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    D = (a64 * a64).sum(1)[:, None] + (b64 * b64).sum(1)[None, :] - 2.0 * (a64 @ b64.T)
+    f = np.argsort(D, axis=1)[:, :2]
+    g = np.argsort(D.T, axis=1)[:, :2]
+    rows, cols = np.arange(na), np.arange(nb)
+    fr = D[rows, f[:, 0]] / np.maximum(D[rows, f[:, 1]], 1e-30)
+    gr = D.T[cols, g[:, 0]] / np.maximum(D.T[cols, g[:, 1]], 1e-30)
+    want = np.full(na, -1)
+    sure = np.zeros(na, bool)                      # decisions with a margin (f32 vs f64 distances)
+    for i in range(na):
+        j = f[i, 0]
+        ok = fr[i] < thr * thr and g[j, 0] == i and gr[j] < thr * thr
+        want[i] = j if ok else -1
+        sure[i] = abs(fr[i] - thr * thr) > 1e-3 and abs(gr[j] - thr * thr) > 1e-3
+    assert (want >= 0).sum() > 20
+    np.testing.assert_array_equal(got[sure], want[sure])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [160, 512])
 def test_config5_two_volumes_match_and_register(n):
     """BASELINE configs[4]: detect + describe two volumes, match, RANSAC affine.  The second

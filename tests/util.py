@@ -47,3 +47,23 @@ def rel_err(a, b):
     if not m.any():
         return 0.0
     return float((np.abs(a - b)[m] / den[m]).max())
+
+
+def desc_projection(h):
+    """The projection oracle/make_golden.py stores as `desc_proj` (same seed, same matrix)."""
+    P = np.random.default_rng(20240768).standard_normal((768, 8))
+    P /= np.linalg.norm(P, axis=0, keepdims=True)
+    return np.ascontiguousarray(h, np.float64) @ P
+
+
+def assert_desc_projection(hist, want_proj, rtol=1e-5):
+    """Every row of `hist` (N x 768) against the reference's projected rows: each of the 8
+    projections within rtol * |row|_2 (unit projection vectors: an elementwise relative error e
+    moves a projection by at most e * |row|_2; mass in a wrong bin moves it by far more)."""
+    hist = np.ascontiguousarray(hist, np.float64)
+    assert want_proj.shape == (len(hist), 8)
+    norm = np.sqrt((hist * hist).sum(axis=1))
+    err = np.abs(desc_projection(hist) - want_proj).max(axis=1)
+    bad = np.nonzero(err > rtol * norm)[0]
+    assert len(bad) == 0, "rows %s: projection error %s of row norm" % (bad[:8], (err / norm)[bad[:8]])
+    return float((err / np.maximum(norm, 1e-30)).max())
