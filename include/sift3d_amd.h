@@ -385,6 +385,26 @@ SIFT3D_AMD_API int
 sift3d_hip_orient(const sift3d_hip_level *d_levels, const sift3d_hip_cand *d_cand,
                   uint32_t n, double corner_thresh, float *d_R, int32_t *d_keep,
                   void *stream);
+/* The same with PARALLEL window sums.  Per level a table of the window's voxel offsets and weights is
+ * built (a candidate sits on a voxel, so the reference's per-voxel window expressions depend on the
+ * level alone); every lane keeps private double sums of its voxels, a fixed butterfly adds them;
+ * every decision (sift.c:997, 1011-1015, 1100) and the float casts of the eigenvectors are accepted
+ * only when they hold for every value the reference's serial sums can have, and the remaining
+ * candidates (a few per cent) are re-run with the serial sums: keypoint lists and R are those of
+ * sift3d_hip_orient bit for bit.  d_tab: device scratch of sift3d_hip_orient_tab_bytes(nlevels,
+ * max_cand) bytes (tables, launch plan, ten double sums per candidate, list of the undecided).  The
+ * caller ZEROES it once after allocating it: a level's table is kept from call to call while the
+ * level's scale, units and strides stay the same (a validity mark + the parameters sit in its
+ * header).  nlevels = entries of d_levels; a call with n > max_cand takes the serial path. */
+SIFT3D_AMD_API size_t sift3d_hip_orient_tab_bytes(int nlevels, uint32_t max_cand);
+SIFT3D_AMD_API int
+sift3d_hip_orient_tab(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_cand *d_cand,
+                      uint32_t n, double corner_thresh, float *d_R, int32_t *d_keep, void *d_tab,
+                      uint32_t max_cand, void *stream);
+/* 1: sift3d_hip_orient_tab runs the serial sums for every candidate (= sift3d_hip_orient); 0
+ * (default): as described above.  Returns the previous mode; any other argument only queries.
+ * Process-wide (tests, A/B measurements). */
+SIFT3D_AMD_API int sift3d_hip_orient_mode(int mode);
 
 typedef struct {
     float R[9];

@@ -135,6 +135,8 @@ struct _sift3d_detector {
     void *d_work2;         /* extrema work areas of octaves >= 1 (kept between the two phases) */
     size_t work2_off[64], work2_bytes;
     float *d_wlut;         /* per-level window-weight tables of the descriptor kernel */
+    void *d_otab;          /* window tables + per-candidate sums of the orientation kernels */
+    size_t otab_bytes;
     sift3d_hip_kp *d_kp, *h_kp;
     uint32_t kp_cap;
     int have_pyramid;
@@ -904,6 +906,9 @@ static void free_device_pyramid(sift3d_detector *d)
     d->work2_bytes = 0;
     sift3d_hip_free(d->d_wlut);
     d->d_wlut = NULL;
+    sift3d_hip_free(d->d_otab);
+    d->d_otab = NULL;
+    d->otab_bytes = 0;
     d->d_im = d->d_tmp_a = d->d_tmp_b = d->d_scalars = NULL;
     d->d_levels = NULL;
     d->d_work = NULL;
@@ -1551,8 +1556,19 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
 
     /* assign_orientations, sift.c:1109-1167 */
     if (count) {
-        if (sift3d_hip_orient(d->d_levels, d->d_cand, count, d->corner_thresh, d->d_R, d->d_keep,
-                              d->stream) ||
+        /* scratch of the orientation kernels: sized by the level count and the candidate capacity */
+        const size_t need = sift3d_hip_orient_tab_bytes(d->num_octaves * d->ngl, d->cand_cap);
+        if (need > d->otab_bytes) {
+            sift3d_hip_free(d->d_otab);
+            d->otab_bytes = 0;
+            d->d_otab = sift3d_hip_malloc(need);
+            /* zeroed once: the tables carry a validity mark (they are kept between calls) */
+            if (!d->d_otab || sift3d_hip_memset(d->d_otab, 0, need, d->stream))
+                return SIFT3D_FAILURE;
+            d->otab_bytes = need;
+        }
+        if (sift3d_hip_orient_tab(d->d_levels, d->num_octaves * d->ngl, d->d_cand, count, d->corner_thresh,
+                                  d->d_R, d->d_keep, d->d_otab, d->cand_cap, d->stream) ||
             sift3d_hip_memcpy_d2h(d->h_cand, d->d_cand, sizeof(sift3d_hip_cand) * (size_t)count,
                                   d->stream) ||
             sift3d_hip_memcpy_d2h(d->h_R, d->d_R, sizeof(float) * 9 * (size_t)count, d->stream) ||

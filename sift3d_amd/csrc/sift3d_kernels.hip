@@ -21,6 +21,7 @@
 #include <cstring>
 
 #include "sift3d_kernels_common.h"
+#include <cstdlib>
 #include "sift3d_math.h"
 #include "synth.h"
 
@@ -1562,19 +1563,14 @@ __device__ __forceinline__ void grad_iso(const sift3d_hip_level &L, int x, int y
 // order by nine accumulator lanes (six double structure-tensor sums, three float gradient
 // sums), which makes every sum bit-identical to the serial CPU loop.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restrict__ levels,
-                                               const sift3d_hip_cand *__restrict__ cand, uint32_t n,
-                                               double corner_thresh, float *__restrict__ Rout,
-                                               int32_t *__restrict__ keep)
+__device__ __forceinline__ void orient_serial(const sift3d_hip_level *__restrict__ levels,
+                                              const sift3d_hip_cand *__restrict__ cand, uint32_t ci,
+                                              double corner_thresh, float *__restrict__ Rout,
+                                              int32_t *__restrict__ keep)
 {
     // rows padded by 16 bytes: the accumulator lanes' 16-byte reads fall on different banks
     __shared__ __attribute__((aligned(16))) double td[6][66];
     __shared__ __attribute__((aligned(16))) float tf[3][68];
-    if (blockIdx.x >= n)
-        return;
-    // candidates arrive in (o, s, z, y, x) order and the window grows with s: walking the list
-    // backwards starts the widest windows first (longest-job-first, short kernel tail)
-    const uint32_t ci = n - 1 - blockIdx.x;
     const int lane = threadIdx.x;
     const sift3d_hip_cand C = cand[ci];
     const sift3d_hip_level L = levels[C.tag];
@@ -1776,6 +1772,602 @@ __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restric
         Rout[(size_t)ci * 9 + lane] = R[lane];
     if (lane == 0)
         keep[ci] = kept;
+}
+
+#ifdef SIFT3D_AMD_DIAG
+__device__ unsigned long long g_orient_undecided;   // candidates re-run by k_orient_fix (profiles/)
+#endif
+
+// every candidate with the reference's serial sums (the original path; sift3d_hip_orient_mode(1))
+__global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restrict__ levels,
+                                               const sift3d_hip_cand *__restrict__ cand, uint32_t n,
+                                               double corner_thresh, float *__restrict__ Rout,
+                                               int32_t *__restrict__ keep)
+{
+    if (blockIdx.x >= n)
+        return;
+    // candidates arrive in (o, s, z, y, x) order and the window grows with s: walking the list
+    // backwards starts the widest windows first (longest-job-first, short kernel tail)
+    orient_serial(levels, cand, n - 1 - blockIdx.x, corner_thresh, Rout, keep);
+}
+
+// the candidates k_orient_decide left undecided (its list: count, then indices), with the serial
+// sums: one wave per window, so the kernel lasts about as long as the longest of them
+__global__ __launch_bounds__(64) void k_orient_fix(const sift3d_hip_level *__restrict__ levels,
+                                                   const sift3d_hip_cand *__restrict__ cand, uint32_t n,
+                                                   double corner_thresh, float *__restrict__ Rout,
+                                                   int32_t *__restrict__ keep,
+                                                   const uint32_t *__restrict__ undecided)
+{
+    const uint32_t cnt = min(undecided[0], n);
+#ifdef SIFT3D_AMD_DIAG
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        atomicAdd(&g_orient_undecided, (unsigned long long)cnt);
+#endif
+    for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {      // wave-uniform
+        orient_serial(levels, cand, undecided[1 + i], corner_thresh, Rout, keep);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// assign_eig_ori + assign_orientation_thresh with PARALLEL sums and decisions by margin.
+//
+// The reference adds the window's terms in scan order (sift.c:978-990): six double sums (the
+// structure tensor A) and three float sums (the window gradient vd_win).  Reproducing those bits
+// needs a serial chain per candidate (orient_serial above: nine lanes work, 55 wait).  But the
+// sums only feed (a) three threshold decisions (sift.c:997, 1011-1015, 1100) and (b) the float
+// casts of two eigenvectors (sift.c:1025).  So: every lane keeps private double sums of its own
+// voxels, a fixed butterfly adds them (reproducible), and each decision is taken only when it
+// holds for EVERY value the serial sums can have; otherwise the candidate is marked undecided
+// (keep = 2) and k_orient_fix runs it through orient_serial.  What "can have" means:
+//   float sums   a serial float sum of n terms differs from the exact sum by at most
+//                (n - 1) 2^-24 sum|t_i| (first order; the parallel double sum of the exact
+//                products is exact to ~2^-53 relative): e_k = (n + 2) 2^-24 sum|g_k w|, with
+//                sum|g_k w| <= sqrt(A_kk sum w) (Cauchy-Schwarz), |e| = the 2-norm of e;
+//   tensor       a serial double sum of n terms lies within n 2^-53 sum|terms| of the exact one
+//                (one rounding per term, one per add), the parallel one within ~110 2^-53 of it;
+//                sum|g_i g_j w| <= (A_ii + A_jj) / 2, so the Frobenius norm of the difference is
+//                <= 1.6 n 2^-53 trace A: E = (2 n + 256) 2^-53 trace A (the 256: the parallel
+//                sum's and Jacobi's own backward error); eigenvalues move by <= E (Weyl),
+//                eigenvector entries by <= 2 E / gap (Davis-Kahan), gap = distance to the
+//                nearest other eigenvalue;
+//   R            a kept candidate's R is written only if all six eigenvector entries round to the
+//                same float over [q - d, q + d], d = 2.5 E / gap + 4e-16, and the sign of
+//                vd_win . v cannot flip (|cos| >= margin) -- so R is the serial path's R bit for bit.
+// Result: keypoint lists and R identical to the serial kernel (tests: both modes, all fixtures);
+// ~1-2 % of the candidates take the second kernel.
+// ---------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// sum over the 64 lanes, the same on every lane, in a fixed order
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+    v += dpp_d<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_d<0x141>(v);       // row_half_mirror
+    v += dpp_d<0x140>(v);       // row_mirror: every lane of a row holds the row's sum
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0),
+                                       __builtin_amdgcn_readlane(__double2loint(v), 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16),
+                                       __builtin_amdgcn_readlane(__double2loint(v), 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32),
+                                       __builtin_amdgcn_readlane(__double2loint(v), 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48),
+                                       __builtin_amdgcn_readlane(__double2loint(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// Window table of a level: the voxels inside the orientation sphere around a centre voxel, as
+// QUADS of up to four x-consecutive voxels, in the reference's scan order (l, j, i ascending),
+// with their Gaussian weights.  A keypoint candidate sits ON a voxel, so (float)x - cx is the
+// exact integer i and the reference's per-voxel expressions (sift.c:102-106, 972) depend on the
+// level alone: every candidate of a level walks the same list (minus what its clipped box cuts
+// off) -- no per-plane rectangles, no sphere test, few empty lanes; and a lane that owns four
+// consecutive voxels fetches their 24 gradient samples with five 16-byte loads and one 8-byte
+// load instead of 24 4-byte gathers (the L1 address path, not arithmetic, bounds this kernel).
+// Table t lives at t * ORI_TAB_STRIDE bytes:
+//   header   u32 quads (ORI_TAB_NONE: no table -- sphere too large), i32 imin, imax, jmin, jmax, lmin,
+//            lmax (extent of the sphere), u32 voxels, at byte 32: double sum of the weights, words 10,
+//            11: first and one-past-last candidate of the level (k_orient_groups), word 12: largest
+//            i of a quad slot (a row's last quad may reach up to three voxels beyond the sphere),
+//            word 13: valid mark, bytes 64..111: the level parameters the table was built for
+//   meta     8 bytes per quad from byte ORI_TAB_HEAD: (i0 + 512) | (j + 512) << 10 | (l + 512) << 20
+//            | (len - 1) << 30, and i0 + nx * (j + ny * l) (offset in floats from the centre voxel)
+//   weights  16 bytes per quad from byte ORI_TAB_HEAD + 8 * ORI_TAB_CAP (0 beyond len)
+constexpr uint32_t ORI_TAB_CAP = 8192, ORI_TAB_NONE = 0xffffffffu;
+constexpr int ORI_TAB_ROWS = 4096;               // rows (j, l) of the search box
+constexpr size_t ORI_TAB_HEAD = 128, ORI_TAB_STRIDE = ORI_TAB_HEAD + (size_t)ORI_TAB_CAP * 24;
+constexpr int ORI_CPW = 4;                       // candidates (waves) per workgroup of k_orient_sums
+constexpr int ORI_PLAN_MAX = 62;                 // levels with a launch plan (4 words each after the count)
+
+__global__ __launch_bounds__(256) void k_orient_table(const sift3d_hip_level *__restrict__ levels, int nlevels,
+                                                      unsigned char *__restrict__ tabs)
+{
+    const int t = blockIdx.x;
+    if (t >= nlevels)
+        return;
+    const sift3d_hip_level L = levels[t];
+    unsigned char *tab = tabs + (size_t)t * ORI_TAB_STRIDE;
+    // A table depends on the level's scale, units and row / plane strides only: when the scratch still
+    // holds the table of exactly these (the usual case: one detector, one image size), keep it.  The
+    // scratch is zeroed when it is allocated, so the signature of a fresh buffer never matches.
+    {
+        uint32_t *head = reinterpret_cast<uint32_t *>(tab);
+        const double *sig = reinterpret_cast<const double *>(tab + 64);
+        const bool same = head[13] == 0x53494654u && sig[0] == L.sd && sig[1] == (double)L.ux &&
+                          sig[2] == (double)L.uy && sig[3] == (double)L.uz && sig[4] == (double)L.nx &&
+                          sig[5] == (double)L.ny;                     // block-uniform
+        if (same) {
+            if (threadIdx.x == 0)
+                head[10] = head[11] = 0;
+            return;
+        }
+    }
+    uint2 *meta = reinterpret_cast<uint2 *>(tab + ORI_TAB_HEAD);
+    float4 *wts = reinterpret_cast<float4 *>(tab + ORI_TAB_HEAD + (size_t)ORI_TAB_CAP * 8);
+    const double sigma = 1.5 * L.sd;            // ori_sig_fctr, sift.c:1125
+    const double rad = sigma * 3.0;             // ori_rad_fctr, sift.c:936
+    const double rad2 = rad * rad, sig2 = sigma * sigma;
+    // half extents of the search box in voxels (+2: safely beyond the sphere)
+    const double ex = rad / (double)L.ux + 2.0, ey = rad / (double)L.uy + 2.0, ez = rad / (double)L.uz + 2.0;
+    bool fits = ex < 500.0 && ey < 500.0 && ez < 500.0 && ex > 0.0 && ey > 0.0 && ez > 0.0;
+    const int mx = fits ? (int)ex : 0, my = fits ? (int)ey : 0, mz = fits ? (int)ez : 0;
+    const int wy = 2 * my + 1, wz = 2 * mz + 1, rows = wy * wz;
+    fits = fits && rows <= ORI_TAB_ROWS;
+    // per row: first in-sphere i and the number of in-sphere voxels (an interval: sq grows with |i|),
+    // then the position of the row's first quad
+    __shared__ short rfirst[ORI_TAB_ROWS], rlen[ORI_TAB_ROWS];
+    __shared__ uint32_t rpos[ORI_TAB_ROWS];
+    __shared__ int ext[6], qmax;
+    __shared__ uint32_t tot[2];
+    __shared__ double wpart[256];
+    if (threadIdx.x == 0) {
+        ext[0] = ext[2] = ext[4] = 1 << 20;
+        ext[1] = ext[3] = ext[5] = qmax = -(1 << 20);
+    }
+    auto in_sphere = [&](int i, int j, int l, float &sq) -> bool {
+        const float dx = (float)i * L.ux, dy = (float)j * L.uy, dz = (float)l * L.uz;   // sift.c:102-104
+        sq = dx * dx + dy * dy + dz * dz;                                               // sift.c:105
+        return !((double)sq > rad2);                                                    // sift.c:106
+    };
+    __syncthreads();
+    for (int r = threadIdx.x; fits && r < rows; r += 256) {
+        const int j = r % wy - my, l = r / wy - mz;
+        int first = 0, len = 0;
+        for (int i = -mx; i <= mx; i++) {
+            float sq;
+            if (in_sphere(i, j, l, sq)) {
+                if (!len)
+                    first = i;
+                len++;
+            }
+        }
+        rfirst[r] = (short)first;
+        rlen[r] = (short)len;
+        if (len) {
+            atomicMin(&ext[0], first); atomicMax(&ext[1], first + len - 1);
+            atomicMax(&qmax, first + 4 * ((len + 3) / 4) - 1);
+            atomicMin(&ext[2], j); atomicMax(&ext[3], j);
+            atomicMin(&ext[4], l); atomicMax(&ext[5], l);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t q = 0, v = 0;
+        for (int r = 0; fits && r < rows; r++) {
+            rpos[r] = q;
+            q += (uint32_t)(rlen[r] + 3) / 4;
+            v += (uint32_t)rlen[r];
+        }
+        tot[0] = q;
+        tot[1] = v;
+    }
+    __syncthreads();
+    const bool ok = fits && tot[0] <= ORI_TAB_CAP;
+    double wacc = 0.0;
+    for (int r = threadIdx.x; ok && r < rows; r += 256) {
+        const int j = r % wy - my, l = r / wy - mz, first = rfirst[r], len = rlen[r];
+        for (int q = 0; 4 * q < len; q++) {
+            const int i0 = first + 4 * q, n4 = min(4, len - 4 * q);
+            float w[4];
+            for (int k = 0; k < 4; k++) {
+                float sq;
+                in_sphere(i0 + k, j, l, sq);
+                w[k] = k < n4 ? s3d_expf((float)(-0.5 * (double)sq / sig2)) : 0.0f;         // sift.c:972
+                wacc += (double)w[k];
+            }
+            meta[rpos[r] + q] = make_uint2((uint32_t)(i0 + 512) | ((uint32_t)(j + 512) << 10) |
+                                               ((uint32_t)(l + 512) << 20) | ((uint32_t)(n4 - 1) << 30),
+                                           (uint32_t)(i0 + L.nx * (j + L.ny * l)));
+            wts[rpos[r] + q] = make_float4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    wpart[threadIdx.x] = wacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double wtot = 0.0;
+        for (int k = 0; k < 256; k++)
+            wtot += wpart[k];
+        uint32_t *head = reinterpret_cast<uint32_t *>(tab);
+        head[0] = ok ? tot[0] : ORI_TAB_NONE;
+        for (int k = 0; k < 6; k++)
+            head[1 + k] = (uint32_t)ext[k];
+        head[7] = tot[1];
+        *reinterpret_cast<double *>(tab + 32) = wtot;
+        head[10] = head[11] = 0;
+        head[12] = (uint32_t)qmax;
+        double *sig = reinterpret_cast<double *>(tab + 64);
+        sig[0] = L.sd; sig[1] = (double)L.ux; sig[2] = (double)L.uy; sig[3] = (double)L.uz;
+        sig[4] = (double)L.nx; sig[5] = (double)L.ny;
+        __threadfence();
+        head[13] = 0x53494654u;                                       // table valid
+    }
+}
+
+// Launch plan of k_orient_fast.  The candidates arrive sorted by (level, z, y, x).  Workgroups go
+// to the eight XCDs in rotation (workgroup b runs on XCD b % 8), and every XCD has its own L2: if
+// consecutive candidates went to consecutive workgroups, all eight XCDs would walk the whole
+// volume and each would fetch it into its own L2 (measured: 13 GB of L2 fills for 1.8 GB of
+// level data -- the fabric, not arithmetic, then bounds the kernel).  So each level's candidates
+// are cut into eight contiguous runs (= eight Z slabs of the level) and XCD k takes run k:
+// level g owns the workgroups [P, P + 8 ceil(q / CPW)), q = ceil(m / 8), and wave w of workgroup
+// P + 8 r + k handles candidate S + k q + CPW r + w (a workgroup is CPW independent waves: 160 000
+// one-wave workgroups cost more to dispatch than their windows take to sum).  k_orient_groups finds S and m (first / last candidate of a level),
+// k_orient_plan lays the levels out, widest windows (highest level index) first.
+__global__ __launch_bounds__(256) void k_orient_groups(const sift3d_hip_cand *__restrict__ cand, uint32_t n,
+                                                       unsigned char *__restrict__ tabs, int nlevels)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const int tag = cand[i].tag;
+    if (tag < 0 || tag >= nlevels)
+        return;
+    uint32_t *head = reinterpret_cast<uint32_t *>(tabs + (size_t)tag * ORI_TAB_STRIDE);
+    if (i == 0 || cand[i - 1].tag != tag)
+        head[10] = i;
+    if (i == n - 1 || cand[i + 1].tag != tag)
+        head[11] = i + 1;
+}
+
+__global__ __launch_bounds__(64) void k_orient_plan(unsigned char *__restrict__ tabs, int nlevels)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    uint32_t *plan = reinterpret_cast<uint32_t *>(tabs + (size_t)nlevels * ORI_TAB_STRIDE);
+    uint32_t P = 0, G = 0;
+    for (int t = nlevels - 1; t >= 0 && G < ORI_PLAN_MAX; t--) {
+        const uint32_t *head = reinterpret_cast<const uint32_t *>(tabs + (size_t)t * ORI_TAB_STRIDE);
+        const uint32_t S = head[10], m = head[11] - head[10];
+        if (!m)
+            continue;
+        const uint32_t q = (m + 7) / 8;
+        plan[1 + 4 * G + 0] = P;
+        plan[1 + 4 * G + 1] = S;
+        plan[1 + 4 * G + 2] = m;
+        plan[1 + 4 * G + 3] = q;
+        P += 8 * ((q + ORI_CPW - 1) / ORI_CPW);
+        G++;
+    }
+    plan[0] = G;
+}
+
+// OWAVES waves share one candidate (chunk c of its quad list goes to wave c % OWAVES).  Measured with
+// 4: no faster than 1 -- neither the sample loads nor the arithmetic of the loop set this kernel's
+// time (ablations in profiles/), the per-candidate epilogue did, which is why the decisions now run
+// one candidate per LANE in k_orient_decide.
+constexpr int OWAVES = 1;
+constexpr int ORI_SUMS = 10;   // doubles per candidate: A00 A01 A02 A11 A12 A22, sum g w (x, y, z), voxels
+__global__ __launch_bounds__(64 * ORI_CPW) void k_orient_sums(const sift3d_hip_level *__restrict__ levels,
+                                                    const sift3d_hip_cand *__restrict__ cand, uint32_t n,
+                                                    const unsigned char *__restrict__ tabs, int nlevels,
+                                                    double *__restrict__ sums
+#ifdef SIFT3D_AMD_DIAG
+                                                    , int ablate
+#endif
+                                                    )
+{
+    // which candidate: see k_orient_plan (wave-uniform, scalar loads)
+    uint32_t ci = 0xffffffffu;
+    {
+        const uint32_t *plan = reinterpret_cast<const uint32_t *>(tabs + (size_t)nlevels * ORI_TAB_STRIDE);
+        const uint32_t G = plan[0], b = blockIdx.x;
+        const uint32_t wave = threadIdx.x >> 6;
+        for (uint32_t g = 0; g < G; g++) {
+            const uint32_t P = plan[1 + 4 * g], S = plan[2 + 4 * g], m = plan[3 + 4 * g], q = plan[4 + 4 * g];
+            const uint32_t nwg = 8 * ((q + ORI_CPW - 1) / ORI_CPW);
+            if (b >= P && b < P + nwg) {
+                const uint32_t j = b - P, k = j % 8, r = (j / 8) * ORI_CPW + wave;
+                if (r < q && k * q + r < m)
+                    ci = S + k * q + r;
+                break;
+            }
+        }
+    }
+    if (ci >= n)
+        return;
+    const int lane = threadIdx.x & 63, wv = 0;      // (the waves of a workgroup are independent)
+    const sift3d_hip_cand C = cand[ci];
+    const sift3d_hip_level L = levels[C.tag];
+    const size_t plane = (size_t)L.nx * L.ny;
+    const int kz_loc = (int)(C.idx / plane);
+    const int rem = (int)(C.idx % plane);
+    const int ky = rem / L.nx, kx = rem % L.nx, kz = kz_loc + L.z_off;
+    const float cx = (float)kx, cy = (float)ky, cz = (float)kz;   // sift.c:1124
+    const double rad = 1.5 * L.sd * 3.0;        // ori_sig_fctr * ori_rad_fctr, sift.c:1125, 936
+    Box B;
+    bounds_d(cx, rad, L.ux, L.nx, B.xs, B.xe);
+    bounds_d(cy, rad, L.uy, L.ny, B.ys, B.ye);
+    bounds_d(cz, rad, L.uz, L.nz_glob, B.zs, B.ze);
+    B.zs = max(B.zs, L.z_off + 1);              // memory safety on Z-slabs, see orient_serial
+    B.ze = min(B.ze, L.z_off + L.nz - 2);
+    const unsigned char *tab = tabs + (size_t)C.tag * ORI_TAB_STRIDE;
+    const uint32_t *head = reinterpret_cast<const uint32_t *>(tab);
+    const uint32_t count = head[0];
+    if (count == ORI_TAB_NONE || count == 0) {  // no table for this level: the serial path decides
+        if (lane == 0)
+            sums[(size_t)ci * ORI_SUMS + 9] = -1.0;
+        return;
+    }
+    // the whole sphere inside the (clipped) window box (sift.c:93-99), and every quad slot (weight 0
+    // beyond the sphere) at least one voxel inside the row?  Then no voxel needs a test and every
+    // load is safe (the box ends one voxel inside the volume).
+    const bool interior = kx + (int)head[1] >= B.xs && kx + (int)head[2] <= B.xe && ky + (int)head[3] >= B.ys &&
+                          ky + (int)head[4] <= B.ye && kz + (int)head[5] >= B.zs && kz + (int)head[6] <= B.ze &&
+                          kx + (int)head[12] <= L.nx - 2;
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned 16-byte load
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    typedef const u2v __attribute__((address_space(1))) *gmeta_p;
+    typedef const f4v __attribute__((address_space(1))) *gwts_p;
+    typedef const f4u __attribute__((address_space(1))) *gf4_p;
+    typedef const f2u __attribute__((address_space(1))) *gf2_p;
+    typedef const float __attribute__((address_space(1))) *gfloat_p;
+    const gmeta_p meta = (gmeta_p) reinterpret_cast<const u2v *>(tab + ORI_TAB_HEAD);
+    const gwts_p wts = (gwts_p) reinterpret_cast<const f4v *>(tab + ORI_TAB_HEAD + (size_t)ORI_TAB_CAP * 8);
+    const int ys32 = L.nx, zs32 = L.nx * L.ny;                      // (nx * ny < 2^31)
+    const gfloat_p centre = (gfloat_p)L.data + ((uint64_t)(uint32_t)zs32 * (uint32_t)kz_loc + (uint32_t)rem);
+    // IM_GET_GRAD_ISO (sift.c:140-145, immacros.h:105-111): g = 0.5f * (v+ - v-), then g *= 1.0f / u.
+    // 0.5f * d is exact, so (0.5f * d) * iu == d * (0.5f * iu) bit for bit.
+    const float hux = 0.5f * (1.0f / L.ux), huy = 0.5f * (1.0f / L.uy), huz = 0.5f * (1.0f / L.uz);
+
+    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;   // tensor (sift.c:978-984)
+    double vx = 0, vy = 0, vz = 0;                                  // sum g w (sift.c:987), exact products
+    double nvox;
+    auto add_voxel = [&](float dxv, float dyv, float dzv, float w) {
+        const float gx = dxv * hux, gy = dyv * huy, gz = dzv * huz;
+        const double dgx = (double)gx, dgy = (double)gy, dgz = (double)gz, dw = (double)w;
+        const double wx_ = dgx * dw, wy_ = dgy * dw, wz_ = dgz * dw;     // exact (24 x 24 bits)
+        a00 = __builtin_fma(wx_, dgx, a00);
+        a01 = __builtin_fma(wx_, dgy, a01);
+        a02 = __builtin_fma(wx_, dgz, a02);
+        a11 = __builtin_fma(wy_, dgy, a11);
+        a12 = __builtin_fma(wy_, dgz, a12);
+        a22 = __builtin_fma(wz_, dgz, a22);
+        vx += wx_; vy += wy_; vz += wz_;
+    };
+    // the four voxels at p .. p + 3 with weights w: 24 samples in six loads
+    struct Quad {
+        f4u ra, yp, ym, zp, zm;
+        f2u rb;
+    };
+    auto load_quad = [&](gfloat_p p, Quad &q) {
+        q.ra = *(gf4_p)(p - 1);
+        q.rb = *(gf2_p)(p + 3);
+        q.yp = *(gf4_p)(p + ys32);
+        q.ym = *(gf4_p)(p - ys32);
+        q.zp = *(gf4_p)(p + zs32);
+        q.zm = *(gf4_p)(p - zs32);
+    };
+    auto sum_quad = [&](const Quad &q, f4v w) {
+        add_voxel(q.ra.z - q.ra.x, q.yp.x - q.ym.x, q.zp.x - q.zm.x, w.x);
+        add_voxel(q.ra.w - q.ra.y, q.yp.y - q.ym.y, q.zp.y - q.zm.y, w.y);
+        add_voxel(q.rb.x - q.ra.z, q.yp.z - q.ym.z, q.zp.z - q.zm.z, w.z);
+        add_voxel(q.rb.y - q.ra.w, q.yp.w - q.ym.w, q.zp.w - q.zm.w, w.w);
+    };
+    auto add_quad = [&](gfloat_p p, f4v w) {
+        Quad q;
+#ifdef SIFT3D_AMD_DIAG
+        if (ablate & 1) {            // no sample loads (wrong results): what the arithmetic costs
+            q.ra = q.yp = q.ym = q.zp = q.zm = f4u{ w.x, w.y, w.z, w.w };
+            q.rb = f2u{ w.x, w.y };
+            sum_quad(q, w);
+            return;
+        }
+        if (ablate & 2) {            // loads only (wrong results)
+            load_quad(p, q);
+            vx += (double)(q.ra.x + q.rb.x + q.yp.x + q.ym.x + q.zp.x + q.zm.x + w.x);
+            return;
+        }
+#endif
+        load_quad(p, q);
+        sum_quad(q, w);
+    };
+    const f4v zero4 = { 0.f, 0.f, 0.f, 0.f };
+    if (interior) {
+        // Two chunks of 64 quads per iteration, their table entries requested one iteration ahead:
+        // an iteration then exposes ONE memory round trip (the twelve sample loads of its two chunks,
+        // all in flight together) instead of four (entries, then samples, per chunk) -- this loop is
+        // bound by load latency, not by bytes or arithmetic (profiles/: ablations of either change
+        // nothing).  Idle lanes and chunks beyond the end repeat the last quad with weight 0.
+        const uint32_t last = count - 1;
+        auto slot = [&](uint32_t t0) -> uint32_t { return min(t0 + (uint32_t)lane, last); };
+        u2v mA = meta[slot(0)], mB = meta[slot(64)];
+        f4v wA = wts[slot(0)], wB = wts[slot(64)];
+        for (uint32_t t0 = 0; t0 < count; t0 += 128) {
+            const u2v nA = meta[slot(t0 + 128)], nB = meta[slot(t0 + 192)];     // next iteration's entries
+            const f4v vA = wts[slot(t0 + 128)], vB = wts[slot(t0 + 192)];
+            Quad qA, qB;
+            load_quad(centre + (int)mA.y, qA);
+            load_quad(centre + (int)mB.y, qB);
+            sum_quad(qA, t0 + (uint32_t)lane < count ? wA : zero4);
+            sum_quad(qB, t0 + 64 + (uint32_t)lane < count ? wB : zero4);
+            mA = nA; mB = nB; wA = vA; wB = vB;
+        }
+        nvox = (double)head[7];
+    } else {
+        const uint32_t xr = (uint32_t)(B.xe - B.xs), yr = (uint32_t)(B.ye - B.ys), zr = (uint32_t)(B.ze - B.zs);
+        const bool box_ok = B.xe >= B.xs && B.ye >= B.ys && B.ze >= B.zs;
+        uint32_t cnt = 0;
+        for (uint32_t t0 = 64 * wv; t0 < count && box_ok; t0 += 64 * OWAVES) {
+            const uint32_t t = t0 + (uint32_t)lane;
+            const uint32_t tt = min(t, count - 1);
+            const u2v m = meta[tt];
+            const f4v w4 = wts[tt];
+            const int x0 = kx + (int)(m.x & 1023u) - 512, y = ky + (int)((m.x >> 10) & 1023u) - 512,
+                      z = kz + (int)((m.x >> 20) & 1023u) - 512;
+            const bool row_in = t < count && (uint32_t)(y - B.ys) <= yr && (uint32_t)(z - B.zs) <= zr;
+            float w[4] = { w4.x, w4.y, w4.z, w4.w };
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool in = row_in && (uint32_t)(x0 + k - B.xs) <= xr && w[k] != 0.0f;   // (weights are > 0 inside)
+                w[k] = in ? w[k] : 0.0f;
+                cnt += in ? 1u : 0u;
+                any = any || in;
+            }
+            // the vector loads touch x0 - 1 .. x0 + 4 of five rows (rows y -+ 1, planes z -+ 1 exist for a
+            // row inside the box): safe when all four slots lie at least one voxel inside the row
+            const bool safe = !any || (x0 >= 1 && x0 + 3 <= L.nx - 2);
+            const gfloat_p p = centre + (any ? (int)m.y : 0);
+            if (__ballot(!safe) == 0ull) {
+                if (any) {
+                    const f4v wv = { w[0], w[1], w[2], w[3] };
+                    add_quad(p, wv);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (w[k] != 0.0f) {
+                        const gfloat_p q = p + k;
+                        add_voxel(q[1] - *(q - 1), q[ys32] - *(q - ys32), q[zs32] - *(q - zs32), w[k]);
+                    }
+                }
+            }
+        }
+        nvox = wave_sum_d((double)cnt);
+    }
+    a00 = wave_sum_d(a00); a01 = wave_sum_d(a01); a02 = wave_sum_d(a02);
+    a11 = wave_sum_d(a11); a12 = wave_sum_d(a12); a22 = wave_sum_d(a22);
+    vx = wave_sum_d(vx); vy = wave_sum_d(vy); vz = wave_sum_d(vz);
+    // the sums of this candidate (k_orient_decide takes it from here, one candidate per lane)
+    if (lane < ORI_SUMS) {
+        const double v = lane == 0 ? a00 : lane == 1 ? a01 : lane == 2 ? a02 : lane == 3 ? a11 : lane == 4 ? a12
+                       : lane == 5 ? a22 : lane == 6 ? vx : lane == 7 ? vy : lane == 8 ? vz : nvox;
+        sums[(size_t)ci * ORI_SUMS + lane] = v;
+    }
+}
+
+// The decisions of assign_eig_ori / assign_orientation_thresh on the parallel sums, one candidate
+// per lane (the 3x3 eigen-decomposition and the margins cost a few thousand instructions: done by a
+// whole wave per candidate they took longer than the window sums themselves).
+__global__ __launch_bounds__(64) void k_orient_decide(const sift3d_hip_cand *__restrict__ cand, uint32_t n,
+                                                      double corner_thresh, float *__restrict__ Rout,
+                                                      int32_t *__restrict__ keep,
+                                                      const unsigned char *__restrict__ tabs,
+                                                      const double *__restrict__ sums,
+                                                      uint32_t *__restrict__ undecided)
+{
+    const uint32_t ci = blockIdx.x * 64 + threadIdx.x;
+    if (ci >= n)
+        return;
+    const double *sm = sums + (size_t)ci * ORI_SUMS;
+    const double a00 = sm[0], a01 = sm[1], a02 = sm[2], a11 = sm[3], a12 = sm[4], a22 = sm[5];
+    const double vx = sm[6], vy = sm[7], vz = sm[8], nvox = sm[9];
+    if (nvox < 0.0) {                           // no table for this level: the serial path decides
+        keep[ci] = 2;
+        undecided[1 + atomicAdd(&undecided[0], 1u)] = ci;
+        return;
+    }
+    const double wsum = *reinterpret_cast<const double *>(tabs + (size_t)cand[ci].tag * ORI_TAB_STRIDE + 32);
+    // ---- decisions ----
+    int kept = 1;          // 0 rejected, 1 kept, 2 undecided
+    float R[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const double u24 = 5.9604644775390625e-08, u53 = 1.1102230246251565e-16;
+    // sum|g_k w| <= sqrt(sum g_k^2 w * sum w) (Cauchy-Schwarz; sum w over the whole sphere is an
+    // upper bound for a clipped window too)
+    const double nf = nvox + 2.0;
+    const double ex = nf * u24 * sqrt(a00 * wsum), ey = nf * u24 * sqrt(a11 * wsum), ez = nf * u24 * sqrt(a22 * wsum);
+    const double enorm = sqrt(ex * ex + ey * ey + ez * ez) * 1.0001 + 1e-300;
+    const double vnorm = sqrt(vx * vx + vy * vy + vz * vz);
+    const double T1 = (double)(float)1E-10;                       // sift.c:997 (float compare)
+    {
+        const double lo = fmax(vnorm - enorm, 0.0), hi = vnorm + enorm;
+        if (hi * hi * (1.0 + 1e-5) < T1)
+            kept = 0;                                             // certainly below
+        else if (!(lo * lo * (1.0 - 1e-5) > T1))
+            kept = 2;
+    }
+    if (kept == 1) {
+        double A[9], Q[9], Lm[3];
+        A[0] = a00; A[1] = a01; A[2] = a02; A[4] = a11; A[5] = a12; A[8] = a22;
+        A[3] = a01; A[6] = a02; A[7] = a12;
+        s3d_eigen3(A, Q, Lm);                                     // eigen_Mat_rm, imutil.c:984
+        const double E = (2.0 * nvox + 256.0) * u53 * (a00 + a11 + a22);
+        // sift.c:1011-1015: reject if |L0 / L1| > 0.9 or |L1 / L2| > 0.9
+        const double r01 = fabs(Lm[0]) - 0.90 * fabs(Lm[1]), r12 = fabs(Lm[1]) - 0.90 * fabs(Lm[2]);
+        const double t2 = 4.0 * E + 1e-14 * fabs(Lm[2]);
+        if (r01 > t2 || r12 > t2) {
+            kept = 0;
+        } else if (!(r01 < -t2 && r12 < -t2)) {
+            kept = 2;
+        } else {
+            const float wx = (float)vx, wy = (float)vy, wz = (float)vz;    // ~ the serial float sums
+            const double vlo = fmax(vnorm - enorm, 1e-300);
+            const double margin = 2.02 * enorm / vlo + 1e-5;
+            double corner = 1.7976931348623157e308;               // DBL_MAX, sift.c:1018
+            float v[2][3];
+            bool exact = true;
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int e = 2 - i;
+                const double gap = i == 0 ? Lm[2] - Lm[1] : fmin(Lm[2] - Lm[1], Lm[1] - Lm[0]);
+                const double dq = 2.5 * E / fmax(gap, 1e-300) + 4e-16;
+                float vf[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double q = Q[k * 3 + e];
+                    vf[k] = (float)q;
+                    exact = exact && (float)(q - dq) == (float)(q + dq);
+                }
+                float vx_ = vf[0], vy_ = vf[1], vz_ = vf[2];
+                const double d = (double)(wx * vx_ + wy * vy_ + wz * vz_);         // sift.c:1029
+                const double cos_ang =
+                    d / (double)(sqrtf(vx_ * vx_ + vy_ * vy_ + vz_ * vz_) *
+                                 sqrtf(wx * wx + wy * wy + wz * wz));             // sift.c:1032
+                const double ac = fabs(cos_ang);
+                corner = corner < ac ? corner : ac;                               // sift.c:1036
+                const float sgn = d > 0.0 ? 1.0f : -1.0f;
+                vx_ = vx_ * sgn; vy_ = vy_ * sgn; vz_ = vz_ * sgn;
+                R[0 * 3 + i] = vx_; R[1 * 3 + i] = vy_; R[2 * 3 + i] = vz_;
+                v[i][0] = vx_; v[i][1] = vy_; v[i][2] = vz_;
+            }
+            R[0 * 3 + 2] = v[0][1] * v[1][2] - v[0][2] * v[1][1];                 // sift.c:1054
+            R[1 * 3 + 2] = v[0][2] * v[1][0] - v[0][0] * v[1][2];
+            R[2 * 3 + 2] = v[0][0] * v[1][1] - v[0][1] * v[1][0];
+            // sift.c:1100: reject if corner < corner_thresh.  Kept only when the serial value is
+            // certainly >= the threshold AND far enough from 0 for the signs above (margin)
+            if (corner < corner_thresh - margin)
+                kept = 0;
+            else if (!(corner >= corner_thresh + margin && corner > margin && exact))
+                kept = 2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        Rout[(size_t)ci * 9 + k] = kept == 1 ? R[k] : 0.0f;
+    keep[ci] = kept;
+    // the list of the undecided (its order varies from run to run; every entry is computed on its
+    // own, so the results do not)
+    if (kept == 2)
+        undecided[1 + atomicAdd(&undecided[0], 1u)] = ci;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2398,6 +2990,28 @@ int sift3d_hip_extrema_gauss6_phase(const float *const *d_g, const float *d_absm
     return SIFT3D_SUCCESS;
 }
 
+#ifdef SIFT3D_AMD_DIAG
+// diagnostic build only: candidates k_orient_fix re-ran since the last call
+__attribute__((visibility("default"))) unsigned long long sift3d_amd_diag_orient_undecided(void)
+{
+    unsigned long long v = 0, z = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_orient_undecided), sizeof(v));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_orient_undecided), &z, sizeof(z));
+    return v;
+}
+#endif
+
+static int g_orient_mode = 0;
+
+int sift3d_hip_orient_mode(int mode)
+{
+    const int prev = g_orient_mode;
+    if (mode == 0 || mode == 1)
+        g_orient_mode = mode;
+    return prev;
+}
+
 int sift3d_hip_orient(const sift3d_hip_level *d_levels, const sift3d_hip_cand *d_cand, uint32_t n,
                       double corner_thresh, float *d_R, int32_t *d_keep, void *stream)
 {
@@ -2405,6 +3019,53 @@ int sift3d_hip_orient(const sift3d_hip_level *d_levels, const sift3d_hip_cand *d
         return SIFT3D_SUCCESS;
     hipLaunchKernelGGL(k_orient, dim3(n), dim3(64), 0, (hipStream_t)stream, d_levels, d_cand, n,
                        corner_thresh, d_R, d_keep);
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+// tables + launch plan (rounded up to 256 bytes), then ORI_SUMS doubles per candidate
+static size_t orient_tab_head_bytes(int nlevels)
+{
+    return (((size_t)nlevels * ORI_TAB_STRIDE + 4 * (1 + 4 * ORI_PLAN_MAX)) + 255) & ~(size_t)255;
+}
+
+// ... then ORI_SUMS doubles per candidate, then the list of the undecided (count + indices)
+size_t sift3d_hip_orient_tab_bytes(int nlevels, uint32_t max_cand)
+{
+    return nlevels > 0 ? orient_tab_head_bytes(nlevels) + sizeof(double) * ORI_SUMS * (size_t)max_cand +
+                             sizeof(uint32_t) * ((size_t)max_cand + 1)
+                       : 0;
+}
+
+int sift3d_hip_orient_tab(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_cand *d_cand,
+                          uint32_t n, double corner_thresh, float *d_R, int32_t *d_keep, void *d_tab,
+                          uint32_t max_cand, void *stream)
+{
+    if (!n)
+        return SIFT3D_SUCCESS;
+    if (g_orient_mode == 1 || !d_tab || nlevels < 1 || nlevels > ORI_PLAN_MAX || n > max_cand)
+        return sift3d_hip_orient(d_levels, d_cand, n, corner_thresh, d_R, d_keep, stream);
+    // window tables of all levels, parallel sums with decisions by margin, then the undecided
+    // candidates with the serial sums
+    hipLaunchKernelGGL(k_orient_table, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, d_levels, nlevels,
+                       (unsigned char *)d_tab);
+    hipLaunchKernelGGL(k_orient_groups, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_cand, n,
+                       (unsigned char *)d_tab, nlevels);
+    hipLaunchKernelGGL(k_orient_plan, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned char *)d_tab, nlevels);
+    // (every level's share of the grid is rounded up to a multiple of 8 workgroups)
+    double *d_sums = reinterpret_cast<double *>((unsigned char *)d_tab + orient_tab_head_bytes(nlevels));
+    uint32_t *d_und = reinterpret_cast<uint32_t *>(d_sums + (size_t)ORI_SUMS * max_cand);
+    HIPCHK(hipMemsetAsync(d_und, 0, sizeof(uint32_t), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_orient_sums, dim3((n + ORI_CPW - 1) / ORI_CPW + 16 * (uint32_t)nlevels), dim3(64 * ORI_CPW), 0, (hipStream_t)stream, d_levels,
+                       d_cand, n, (const unsigned char *)d_tab, nlevels, d_sums
+#ifdef SIFT3D_AMD_DIAG
+                       , getenv("SIFT3D_AMD_ORI_ABLATE") ? atoi(getenv("SIFT3D_AMD_ORI_ABLATE")) : 0
+#endif
+                       );
+    hipLaunchKernelGGL(k_orient_decide, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_cand, n,
+                       corner_thresh, d_R, d_keep, (const unsigned char *)d_tab, d_sums, d_und);
+    hipLaunchKernelGGL(k_orient_fix, dim3(n < 8192u ? n : 8192u), dim3(64), 0, (hipStream_t)stream, d_levels,
+                       d_cand, n, corner_thresh, d_R, d_keep, d_und);
     LAUNCH_CHECK();
     return SIFT3D_SUCCESS;
 }

@@ -79,6 +79,8 @@ struct sift3d_amd_sharded {
     void *d_work;
     size_t work_bytes;
     float *d_wlut;
+    void *d_otab;          /* orientation window tables + candidate sums (sift3d_hip_orient_tab) */
+    size_t otab_bytes;
     sift3d_hip_cand *d_cand, *h_cand;
     float *d_R, *h_R;
     int32_t *d_keep, *h_keep;
@@ -168,7 +170,7 @@ void sift3d_amd_sharded_free(sift3d_amd_sharded *S)
     sift3d_hip_free(S->d_levels); sift3d_hip_free(S->d_work); sift3d_hip_free(S->d_work2);
     sift3d_hip_free(S->d_cand);
     sift3d_hip_free(S->d_R); sift3d_hip_free(S->d_keep); sift3d_hip_free(S->d_xchg);
-    sift3d_hip_free(S->d_kp); sift3d_hip_free(S->d_wlut);
+    sift3d_hip_free(S->d_kp); sift3d_hip_free(S->d_wlut); sift3d_hip_free(S->d_otab);
     sift3d_hip_host_free(S->h_cand); sift3d_hip_host_free(S->h_R); sift3d_hip_host_free(S->h_keep);
     sift3d_hip_host_free(S->h_xchg); sift3d_hip_host_free(S->h_kp);
     sift3d_hip_event_destroy(S->ev_x); sift3d_hip_event_destroy(S->ev_halo);
@@ -701,8 +703,18 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
     if (S->world > 1 && S->o_shard > 0 && sift3d_hip_stream_wait_event(S->stream, S->ev_halo))
         return SIFT3D_FAILURE;                           /* the window halos have arrived */
     if (count) {
-        if (sift3d_hip_orient(S->d_levels, S->d_cand, count, S->corner_thresh, S->d_R, S->d_keep,
-                              S->stream) ||
+        const size_t need = sift3d_hip_orient_tab_bytes(S->num_octaves * SH_NGL, S->cand_cap);
+        if (need > S->otab_bytes) {
+            sift3d_hip_free(S->d_otab);
+            S->otab_bytes = 0;
+            S->d_otab = sift3d_hip_malloc(need);
+            /* zeroed once: the tables carry a validity mark (they are kept between calls) */
+            if (!S->d_otab || sift3d_hip_memset(S->d_otab, 0, need, S->stream))
+                return SIFT3D_FAILURE;
+            S->otab_bytes = need;
+        }
+        if (sift3d_hip_orient_tab(S->d_levels, S->num_octaves * SH_NGL, S->d_cand, count, S->corner_thresh,
+                                  S->d_R, S->d_keep, S->d_otab, S->cand_cap, S->stream) ||
             sift3d_hip_memcpy_d2h(S->h_cand, S->d_cand, sizeof(sift3d_hip_cand) * (size_t)count, S->stream) ||
             sift3d_hip_memcpy_d2h(S->h_R, S->d_R, sizeof(float) * 9 * (size_t)count, S->stream) ||
             sift3d_hip_memcpy_d2h(S->h_keep, S->d_keep, sizeof(int32_t) * (size_t)count, S->stream))

@@ -474,6 +474,38 @@ def test_read_image_then_detect(gpu, oracle_mod, tmp_path):
     assert util.rel_err(desc.to_mat_rm(), o.desc_mat()) <= RTOL
 
 
+@pytest.mark.parametrize("case", ["lattice160", "survey96", "aniso", "corner0", "params"])
+def test_orientation_parallel_sums_equal_serial_sums(gpu, oracle_mod, case):
+    """sift3d_hip_orient_mode: the default path (parallel double sums, decisions by margin, serial
+    re-run of the undecided candidates) must give the keypoint list AND the R bits of the path
+    that adds every window in the reference's scan order (sift.c:978-990)."""
+    api, hip, torch = gpu
+    units, kw = (1.0, 1.0, 1.0), {}
+    if case == "lattice160":
+        vol = oracle_mod.synth_lattice(160, seed=21)
+    elif case == "survey96":
+        vol = oracle_mod.synth_survey(96)
+    elif case == "aniso":
+        vol, units = oracle_mod.synth_survey((72, 60, 81)), (1.0, 1.5, 0.7)
+    elif case == "corner0":
+        vol, kw = oracle_mod.synth_lattice(80, seed=5), dict(corner_thresh=0.0, peak_thresh=0.02)
+    else:
+        vol, kw = oracle_mod.synth_survey(64), dict(num_kp_levels=2, sigma0=2.0, sigma_n=1.0,
+                                                    peak_thresh=0.05, corner_thresh=0.3)
+    got = {}
+    try:
+        for mode in (1, 0):
+            hip.orient_mode(mode)
+            det, kp = api.Detector(**kw), api.KeypointStore()
+            assert det.detect_keypoints(api.Image.from_array(vol, units=units), kp) == 0
+            got[mode] = (det.num_candidates(), kp.records())
+    finally:
+        hip.orient_mode(0)
+    assert got[0][0] == got[1][0] and len(got[0][1]) == len(got[1][1]) > 0
+    for f in ("o", "s", "xd", "yd", "zd", "sd", "strength", "R"):
+        np.testing.assert_array_equal(got[0][1][f], got[1][1][f], err_msg=f)
+
+
 def test_repeated_runs_are_bitwise_identical(gpu):
     """The window kernels rely on the issue order of a wave's LDS operations and on block-level
     reductions through atomicMax only: every run must give the same bits."""
