@@ -9,7 +9,8 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsift3d_amd.so")
+# SIFT3D_AMD_LIB: another build of the same library (the sanitizer build, `make -C sift3d_amd/csrc asan`)
+LIB_PATH = os.environ.get("SIFT3D_AMD_LIB") or os.path.join(HERE, "libsift3d_amd.so")
 CSRC = os.path.join(HERE, "csrc")
 
 _lib = None

@@ -134,6 +134,96 @@ class DistTransport:
         pass
 
 
+class ThreadGroup:
+    """What the N thread-ranks of ONE process share (ThreadTransport)."""
+
+    def __init__(self, world):
+        import queue
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.q = {(a, b): queue.Queue() for a in range(world) for b in (a - 1, a + 1) if 0 <= b < world}
+        self.ack = {k: queue.Queue() for k in self.q}
+
+
+class ThreadTransport:
+    """N ranks as N threads of one process on one device: device-to-device copies between the
+    slab drivers, rendezvous through queues / a barrier.  Host-synchronous like DistTransport
+    (every call first drains the caller's stream).  This is how a one-GPU box runs BASELINE
+    configs[3]'s real geometry -- 8 ranks -- without 8 processes on the card (the pool allows 6)."""
+    TIMEOUT = 300
+
+    def __init__(self, group, rank):
+        self.g, self.rank, self.world = group, rank, group.world
+        self.H = hip.lib()
+        self._cb = (_HALO(self._halo), _ARMAX(self._armax), _AGATHER(self._agather))  # keep alive
+        self.t = Transport(self.rank, self.world, None, *self._cb)
+
+    def _sync(self, stream):
+        hip._check(self.H.sift3d_hip_stream_sync(stream), "sync")
+
+    def _halo(self, ctx, send_lo, recv_lo, send_hi, recv_hi, nbytes, stream):
+        try:
+            g, r = self.g, self.rank
+            self._sync(stream)                                   # my planes are final
+            for sp, peer in ((send_lo, r - 1), (send_hi, r + 1)):
+                if sp:
+                    g.q[(r, peer)].put(sp)
+            for rp, peer in ((recv_lo, r - 1), (recv_hi, r + 1)):
+                if rp:
+                    src = g.q[(peer, r)].get(timeout=self.TIMEOUT)
+                    hip._check(self.H.sift3d_hip_memcpy_d2d(rp, src, nbytes, stream), "d2d")
+            self._sync(stream)
+            for rp, peer in ((recv_lo, r - 1), (recv_hi, r + 1)):
+                if rp:
+                    g.ack[(peer, r)].put(1)                      # the sender's planes have been read
+            for sp, peer in ((send_lo, r - 1), (send_hi, r + 1)):
+                if sp:
+                    g.ack[(r, peer)].get(timeout=self.TIMEOUT)
+            return 0
+        except Exception as e:  # a Python exception must not unwind through C
+            print("ThreadTransport.halo (rank %d): %r" % (self.rank, e))
+            return -1
+
+    def _collect(self, mine):
+        g = self.g
+        g.slots[self.rank] = mine
+        g.barrier.wait(self.TIMEOUT)
+        allv = [np.array(v, copy=True) for v in g.slots]
+        g.barrier.wait(self.TIMEOUT)                             # the slots may be reused
+        return allv
+
+    def _armax(self, ctx, dbuf, n, stream):
+        try:
+            a = np.empty(n, np.float32)
+            hip._check(self.H.sift3d_hip_memcpy_d2h(a.ctypes.data, dbuf, 4 * n, stream), "d2h")
+            self._sync(stream)
+            m = np.maximum.reduce(self._collect(a))
+            hip._check(self.H.sift3d_hip_memcpy_h2d(dbuf, m.ctypes.data, 4 * n, stream), "h2d")
+            self._sync(stream)
+            return 0
+        except Exception as e:
+            print("ThreadTransport.allreduce_max (rank %d): %r" % (self.rank, e))
+            return -1
+
+    def _agather(self, ctx, dsend, drecv, nbytes, stream):
+        try:
+            a = np.empty(nbytes, np.uint8)
+            hip._check(self.H.sift3d_hip_memcpy_d2h(a.ctypes.data, dsend, nbytes, stream), "d2h")
+            self._sync(stream)
+            out = np.concatenate(self._collect(a))
+            hip._check(self.H.sift3d_hip_memcpy_h2d(drecv, out.ctypes.data, out.nbytes, stream), "h2d")
+            self._sync(stream)
+            return 0
+        except Exception as e:
+            print("ThreadTransport.allgather (rank %d): %r" % (self.rank, e))
+            return -1
+
+    def close(self):
+        pass
+
+
 class RcclTransport:
     """The library's own RCCL communicator; torch.distributed only carries the unique id."""
 

@@ -204,6 +204,68 @@ def test_config4_1024_sharded_equals_single_gpu():
     torch.cuda.empty_cache()
 
 
+def test_config4_geometry_eight_ranks():
+    """BASELINE configs[3]'s real geometry: EIGHT Z-slabs.  256 x 256 x 1024 gives every rank the
+    128 planes (octave 0) and 64 planes (octave 1, against a ~40-plane window halo) it has at
+    1024^3, o_shard = 2 and the sharded -> replicated transition at octave 2.  The eight ranks are
+    eight threads of this process (the pool allows at most 6 processes on the card), each with its
+    own C slab driver, exchanging through ThreadTransport; every rank's result must equal the
+    single-GPU drop-in API bit for bit."""
+    import threading
+    import torch
+    from sift3d_amd import api, hip, sharded_c
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    world, dims = 8, (256, 256, 1024)
+    nx, ny, nz = dims
+    group = sharded_c.ThreadGroup(world)
+    out, err = [None] * world, []
+
+    def run(rank):
+        try:
+            job = sharded_c.CShardedSift3D(nx, ny, nz, sharded_c.ThreadTransport(group, rank))
+            job.synth(seed=11)
+            job.detect()
+            idx, desc = job.describe()
+            out[rank] = dict(kp=job.keypoints(), idx=idx.copy(), own=job.in_own, o_shard=job.o_shard,
+                             num_octaves=job.num_octaves, ncand=job.ncand,
+                             mat=desc.to_mat_rm() if len(idx) else np.zeros((0, 771), np.float32))
+            job.close()
+        except Exception as e:  # noqa: BLE001
+            err.append((rank, repr(e)))
+            try:
+                group.barrier.abort()
+            except Exception:
+                pass
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(900)
+    assert not err, err
+    assert all(o is not None for o in out)
+    vol = torch.empty((nz, ny, nx), device="cuda")
+    hip.synth_lattice(vol, 0, 11)
+    torch.cuda.synchronize()
+    det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+    assert det.detect_keypoints_device(vol.data_ptr(), nx, ny, nz, kp) == 0
+    assert det.extract_descriptors(kp, desc) == 0
+    k, m = kp.records(), desc.to_mat_rm()
+    assert len(k) > 5000
+    covered = np.zeros(len(k), int)
+    for r, g in enumerate(out):
+        assert g["own"] == (128 * r, 128 * (r + 1)) and g["o_shard"] == 2 and g["num_octaves"] == 6
+        assert g["ncand"] == det.num_candidates()
+        for f in ("o", "s", "xd", "yd", "zd", "sd", "strength", "R"):
+            np.testing.assert_array_equal(g["kp"][f], k[f], err_msg="rank %d field %s" % (r, f))
+        np.testing.assert_array_equal(g["mat"], m[g["idx"]])
+        covered[g["idx"]] += 1
+    np.testing.assert_array_equal(covered, 1)
+    del det, vol
+    torch.cuda.empty_cache()
+
+
 def _worker_rccl1(rank, world, port, dims, outdir):
     sys.path.insert(0, ROOT)
     import torch

@@ -93,6 +93,30 @@ def test_sharded_equals_single(world, dims, cuboid):
         assert int(res[0]["o_shard"]) == 0           # tiny volume: replicated, work split only
 
 
+def test_config4_geometry_eight_ranks_cpu():
+    """BASELINE configs[3]'s slab geometry with EIGHT ranks: 32 x 32 x 1024 gives every rank the 128
+    planes (octave 0) and 64 planes (octave 1) it has at 1024^3, o_shard = 2 and the sharded ->
+    replicated transition at octave 2 -- on the CPU backend with gloo."""
+    import torch.multiprocessing as mp
+    world, dims = 8, (32, 32, 1024)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), dims, d, False), nprocs=world, join=True)
+        res = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(world)]
+    o = _reference(dims)
+    ok, want_mat = o.keypoints(), o.desc_mat()
+    assert len(ok) > 50
+    covered = np.zeros(len(ok), int)
+    for r, g in enumerate(res):
+        assert int(g["o_shard"]) == 2 and int(g["num_octaves"]) == 3
+        assert list(g["bounds"]) == [128 * i for i in range(9)]
+        assert int(g["ncand"]) == len(o.candidates())
+        for f in ("o", "s", "xd", "yd", "zd", "sd", "strength", "R"):
+            np.testing.assert_array_equal(g["kp"][f], ok[f], err_msg="rank %d field %s" % (r, f))
+        np.testing.assert_array_equal(g["mat"], want_mat)
+        covered[g["idx"]] += 1
+    np.testing.assert_array_equal(covered, 1)
+
+
 def test_sharded_wide_windows_equal_single():
     """sigma0 = 2.0 and a 0.7 voxel spacing along z: the descriptor window reaches
     ceil(14.1422 * 2.0 * 2^(2/3) / 0.7) + 2 = 67 planes, far beyond the default 40-plane halo.
