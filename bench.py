@@ -70,10 +70,17 @@ def kernel_microbench(torch, hip, n, reps=10):
     hip.synth_lattice(src, 0, 11)
     out = []
 
-    def row(nm, hw, ax, nbytes, ms, in_pipeline):
-        out.append(dict(kernel=nm, taps=2 * hw + 1, axis=ax, avg_ms=round(ms, 4),
+    def row(nm, hw, ax, nbytes, times_ms, in_pipeline):
+        """One kernel instance: median / min / mean over the reps; a rep slower than 3x the median is
+        an outlier (a stall of the box, not the kernel) and is flagged, not hidden."""
+        t = np.sort(np.asarray(times_ms, np.float64))
+        med = float(np.median(t))
+        out.append(dict(kernel=nm, taps=2 * hw + 1, axis=ax, avg_ms=round(med, 4), min_ms=round(float(t[0]), 4),
+                        mean_ms=round(float(t.mean()), 4), reps=len(t),
+                        outliers=int((t > 3.0 * med).sum()),
                         in_pipeline=in_pipeline, algorithmic_GB=round(nbytes * n ** 3 / 1e9, 4),
-                        achieved_GBs=round(nbytes * n ** 3 / 1e9 / (ms * 1e-3), 1)))
+                        achieved_GBs=round(nbytes * n ** 3 / 1e9 / (med * 1e-3), 1),
+                        frac=round(nbytes * n ** 3 / 1e9 / (med * 1e-3) / HBM_PEAK_GBS, 4)))
 
     for s in sig:
         taps = api.gauss_filter(s)          # the detector's own filter bank
@@ -94,21 +101,21 @@ def kernel_microbench(torch, hip, n, reps=10):
             ev[3 * r + 2].record()
             a, b = b, a
         torch.cuda.synchronize()
-        x_ms = sum(ev[3 * r].elapsed_time(ev[3 * r + 1]) for r in range(reps)) / reps
-        yz_ms = sum(ev[3 * r + 1].elapsed_time(ev[3 * r + 2]) for r in range(reps)) / reps
+        x_ms = [ev[3 * r].elapsed_time(ev[3 * r + 1]) for r in range(reps)]
+        yz_ms = [ev[3 * r + 1].elapsed_time(ev[3 * r + 2]) for r in range(reps)]
         row("k_fir_x_u1<%d>" % hw, hw, 0, 8.0, x_ms, True)
         row("k_fir_yz_u1<%d, 32, %d>" % (hw, 32 if n % 128 == 0 else 16), hw, 12, 16.0, yz_ms, True)   # two 1-D passes = 16 B/voxel
 
         def timed(fn):
             fn()
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+            e[0].record()
+            for r in range(reps):
                 fn()
-            e1.record()
+                e[r + 1].record()
             torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps
+            return [e[r].elapsed_time(e[r + 1]) for r in range(reps)]
 
         # the separate y and z kernels are the fallback / slab-halo path
         hip.synth_lattice(src, 0, 11)       # (the ping-pong above blurred it away)
@@ -205,6 +212,78 @@ def cpu_baseline(n_all=128, n_one=96):
     return out
 
 
+def register_bench(a, torch, api, hip):
+    """BASELINE configs[4]: two 512^3 volumes related by a known rigid motion; a step = detect+describe
+    both + descriptor matching (sift3d_hip_nn2 on the matrix cores, both directions) + RANSAC affine.
+    PARITY UNPINNED (the reference fork removed this stage): validated by recovering the motion."""
+    n = a.size
+    sy, sz = 5, 9
+    vol = torch.empty((n + 24, n + 16, n), device="cuda")
+    hip.synth_lattice(vol, 0, 21)
+    v1 = vol[0:n, 0:n, :].contiguous()
+    v2 = vol[sz:sz + n, sy:sy + n, :].transpose(1, 2).flip(1).contiguous()   # 90 degrees about z + shift
+    del vol
+    torch.cuda.synchronize()
+    dets = [api.Detector(), api.Detector()]
+    kps = [api.KeypointStore(), api.KeypointStore()]
+    descs = [api.DescriptorStore(), api.DescriptorStore()]
+    want = np.array([[0, 1.0, 0, -sy], [-1.0, 0, 0, n - 1], [0, 0, 1.0, -sz]])
+    res = {}
+
+    def step():
+        for v, det, kp, desc in zip((v1, v2), dets, kps, descs):
+            assert det.detect_keypoints_device(v.data_ptr(), n, n, n, kp) == 0
+            assert det.extract_descriptors(kp, desc) == 0
+        t0 = time.perf_counter()
+        m = api.nn_match(descs[0], descs[1], 0.8)
+        t1 = time.perf_counter()
+        hit = np.nonzero(m >= 0)[0]
+        p1 = descs[0].xyz()[hit]
+        p2 = descs[1].xyz()[m[hit]]
+        T, inl = api.ransac_affine(p1, p2, err_thresh=3.0, num_iter=500, seed=5)
+        res.update(match_s=t1 - t0, ransac_s=time.perf_counter() - t1, matches=int(len(hit)),
+                   inliers=int(inl.sum()), T=T, nn2_s=api.nn_match_seconds())
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stat = []
+    for _ in range(a.steps):
+        step()
+        stat.append((res["match_s"], res["ransac_s"], res["nn2_s"]))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    na, nb = len(descs[0]), len(descs[1])
+    nn2 = float(np.median([s[2] for s in stat]))
+    flops = 2.0 * 2.0 * na * nb * 768                      # both directions, multiply + add
+    peak = 157.3                                           # dense f32 MFMA TFLOP/s, MI355X_MICROARCH.md
+    err_R = float(np.abs(res["T"][:, :3] - want[:, :3]).max())
+    err_t = float(np.abs(res["T"][:, 3] - want[:, 3]).max())
+    out = {
+        "metric": "Mvoxel/s two-volume detect+describe+match+RANSAC (float32 volumes resident in HBM)",
+        "value": round(2 * n ** 3 / 1e6 / dt, 2), "unit": "Mvoxel/s", "n_gpus": 1, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(1e3 * dt, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "two %d^3 float32 lattice-blob volumes (the second = the first rotated by 90 "
+                               "degrees about z and shifted): detect+describe both, mutual nearest-neighbour "
+                               "match with ratio 0.8, RANSAC 12-parameter affine" % n,
+                   "parallelism": "single GPU"},
+        "keypoints": [na, nb], "matches": res["matches"], "inliers": res["inliers"],
+        "affine_error": {"linear_part_max": round(err_R, 5), "translation_max_voxels": round(err_t, 4)},
+        "stage_s": {"detect_describe": round(dt - float(np.median([s[0] + s[1] for s in stat])), 6),
+                    "match": round(float(np.median([s[0] for s in stat])), 6),
+                    "ransac": round(float(np.median([s[1] for s in stat])), 6)},
+        "roofline": {"bound": "mfma", "kernel": "k_nn2 (v_mfma_f32_32x32x2_f32), both directions",
+                     "achieved": round(flops / nn2 / 1e12, 2) if nn2 > 0 else None, "peak": peak,
+                     "unit": "TFLOP/s", "frac": round(flops / nn2 / 1e12 / peak, 4) if nn2 > 0 else None,
+                     "traffic": None, "flops": flops, "seconds": round(nn2, 6),
+                     "note": "device seconds of the two sift3d_hip_nn2 calls (HIP events on their stream); "
+                             "parity unpinned: the reference fork removed this stage"},
+    }
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,8 +296,13 @@ def main():
                     help="strong scaling: ONE EDGE^3 volume (BASELINE configs[3]: 1024) cut into "
                          "--gpus Z-slabs, instead of the default 512 planes per GPU")
     ap.add_argument("--no-host", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
-    ap.add_argument("--py-driver", action="store_true",
-                    help="N > 1 / --sharded: use the Python slab driver instead of the C one")
+    ap.add_argument("--rehearse-threads", type=int, default=0, metavar="R",
+                    help="N=1 only: R slab drivers as R threads of this process on the one device "
+                         "(sharded_c.ThreadTransport) -- exercises the N = R code path and geometry where "
+                         "R processes may not share a card; the numbers are not a scaling measurement")
+    ap.add_argument("--register", action="store_true",
+                    help="BASELINE configs[4]: two volumes, detect+describe both, descriptor matching on "
+                         "the matrix cores + RANSAC affine; prints the config-5 line (flops roofline of k_nn2)")
     ap.add_argument("--sharded", action="store_true",
                     help="N=1 only: run the Z-slab driver (C: sift3d_amd_sharded_*) instead of the "
                          "drop-in API, to measure the driver's own overhead")
@@ -250,7 +334,45 @@ def main():
 
     n = a.strong if a.strong else a.size
     nz_total = n if a.strong else n * world
-    if world == 1 and not a.sharded:
+    if a.register:
+        return register_bench(a, torch, api, hip)
+    rt = a.rehearse_threads if world == 1 else 0
+    if rt > 1:
+        # R ranks as R threads: R C slab drivers on this device, exchanging through ThreadTransport
+        import threading
+        from sift3d_amd import sharded_c
+        nz_total = n if a.strong else n * rt
+        grp = sharded_c.ThreadGroup(rt)
+        jobs = [None] * rt
+
+        def _threads(fn):
+            err = []
+
+            def run(r):
+                try:
+                    fn(r)
+                except Exception as e:  # noqa: BLE001
+                    err.append((r, repr(e)))
+                    grp.barrier.abort()
+            th = [threading.Thread(target=run, args=(r,)) for r in range(rt)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if err:
+                raise SystemExit("rehearsal failed: %s" % err)
+
+        def _make(r):
+            jobs[r] = sharded_c.CShardedSift3D(n, n, nz_total, sharded_c.ThreadTransport(grp, r))
+            jobs[r].synth(seed=11)
+        _threads(_make)
+        step = lambda: _threads(lambda r: jobs[r].step())  # noqa: E731
+        stats = lambda: dict(jobs[0].stats(), rehearsal="%d ranks as threads of one process on one device: "  # noqa: E731
+                             "code path and geometry of N = %d, not a scaling measurement" % (rt, rt),
+                             per_rank_max_s={k: round(max(j.breakdown()[k] for j in jobs), 6)
+                                             for k in jobs[0].breakdown()})
+        pyr_time = jobs[0].pyramid_seconds
+    elif world == 1 and not a.sharded:
         vol = torch.empty((n, n, n), device="cuda")
         hip.synth_lattice(vol, 0, 11)
         torch.cuda.synchronize()
@@ -268,25 +390,15 @@ def main():
         pyr_time = lambda: det.timings()["gauss_dev"]  # noqa: E731
     else:
         # The slab driver in C (sift3d_amd/csrc/sift3d_sharded.c) over the library's own RCCL
-        # communicator; rehearsals on one device stage the exchanges through gloo.  The Python
-        # driver (sift3d_amd/sharded.py) remains for configurations the C driver refuses.
-        job = None
-        if not a.py_driver:
-            from sift3d_amd import sharded_c
-            try:
-                if world == 1:
-                    tr = None
-                elif rehearse:
-                    tr = sharded_c.DistTransport()
-                else:
-                    tr = sharded_c.RcclTransport()
-                job = sharded_c.CShardedSift3D(n, n, nz_total, tr)
-            except (ValueError, RuntimeError) as e:
-                sys.stderr.write("bench: C slab driver unavailable (%s), using the Python driver\n" % e)
-                job = None
-        if job is None:
-            from sift3d_amd import sharded
-            job = sharded.ShardedSift3D(n, n, nz_total, dist.group.WORLD if world > 1 else None)
+        # communicator; rehearsals on one device stage the exchanges through gloo.
+        from sift3d_amd import sharded_c
+        if world == 1:
+            tr = None
+        elif rehearse:
+            tr = sharded_c.DistTransport()
+        else:
+            tr = sharded_c.RcclTransport()
+        job = sharded_c.CShardedSift3D(n, n, nz_total, tr)
         job.synth(seed=11)
         step = job.step
         stats = job.stats
@@ -312,6 +424,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    per_rank = None
+    if world > 1 and hasattr(job, "breakdown"):
+        # stage seconds of the last step, max over ranks (so that a scaling curve can be read)
+        bd = job.breakdown()
+        keys = sorted(bd)
+        t = torch.tensor([bd[k] for k in keys], device="cpu" if rehearse else "cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_rank = {k: round(float(v), 6) for k, v in zip(keys, t.tolist())}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -319,7 +439,9 @@ def main():
 
     ms_per_step = 1e3 * dt / a.steps
     value = voxels_per_step / 1e6 / (dt / a.steps)
-    if world == 1:
+    if rt > 1:
+        slabs = " cut into %d Z-slabs" % rt
+    elif world == 1:
         slabs = ""
     elif a.strong:
         slabs = " cut into %d Z-slabs" % world
@@ -334,9 +456,13 @@ def main():
         "config": {"workload": "%dx%dx%d float32 lattice-blob volume%s, detect+describe, default "
                                "parameters (sigma0 1.6, sigma_n 1.15, 3 levels/octave)"
                                % (n, n, nz_total, slabs),
-                   "parallelism": "single GPU" if world == 1 else "z-slab x%d" % world},
+                   "parallelism": ("z-slab x%d (threads of one process, one device)" % rt) if rt > 1 else
+                                  "single GPU" if world == 1 else "z-slab x%d" % world},
     }
     out.update(stats())
+    if per_rank:
+        out["per_rank_max_s"] = per_rank
+        out["transport"] = "gloo rehearsal (ranks share device 0)" if rehearse else "RCCL (ncclSend/Recv, all-reduce, all-gather)"
     # pyramid roofline (whole Gaussian pyramid build, per GPU)
     pbytes = pyramid_algorithmic_bytes(n, n, nz_total // world)
     pt = float(np.median(pyr)) if pyr and pyr[0] else None
@@ -356,7 +482,7 @@ def main():
     # host-resident entry (sift3d_detect_keypoints on a sift3d_make_image volume in pageable host
     # memory): the same K steps timed the same way, H2D copy included.  Reported beside `value`,
     # never as `value`.
-    if world == 1 and not a.sharded and not a.no_host:
+    if world == 1 and not a.sharded and not a.no_host and not rt:
         im = api.Image.from_array(vol.cpu().numpy())
         kp2, desc2 = api.KeypointStore(), api.DescriptorStore()
 
@@ -377,7 +503,7 @@ def main():
                                               "timed region (sift3d_detect_keypoints on a "
                                               "sift3d_image)"}
         del im
-    if world == 1 and not a.no_micro and not a.sharded and not a.strong:
+    if world == 1 and not a.no_micro and not a.sharded and not a.strong and not rt:
         kb = kernel_microbench(torch, hip, n)
         # dominant kernel = the pipeline kernel with the longest launch
         dom = max((k for k in kb if k["in_pipeline"]), key=lambda k: k["avg_ms"])
@@ -408,6 +534,7 @@ def main():
         yz_last = out.get("stage_s", {}).get("yz_last")
         if yz_last:
             out["roofline"]["avg_launch_ms_in_pipeline"] = round(1e3 * yz_last, 4)
+            out["roofline"]["frac_in_pipeline"] = round(dom["algorithmic_GB"] / yz_last / HBM_PEAK_GBS, 4)
             out["roofline"]["in_pipeline_note"] = ("in the step this launch overlaps the octave >= 1 "
                                                    "streams; avg_launch_ms is the kernel alone")
         dpath = os.path.join(ROOT, "profiles", "describe_model.json")

@@ -197,7 +197,10 @@ SIFT3D_AMD_API int sift3d_amd_sharded_describe(sift3d_amd_sharded *, const sift3
                                                sift3d_descriptor_store *desc, int *own_idx,
                                                int *n_own);
 SIFT3D_AMD_API int sift3d_amd_sharded_num_candidates(const sift3d_amd_sharded *);
-/* [0] Gaussian pyramid (device seconds)  [1] detect wall  [2] describe wall */
+/* eight doubles of the last step: [0] Gaussian pyramid (device s, halo exchanges of the blurs inside)
+ * [1] detect wall  [2] describe wall  [3] DoG maxima + extrema (device s, incl. the all-reduce)
+ * [4] wait for the window halos + orientation (device s)  [5] gathers + global keypoint list (host s)
+ * [6] input scaling (device s, incl. the all-reduce)  [7] unused */
 SIFT3D_AMD_API const double *sift3d_amd_sharded_timings(const sift3d_amd_sharded *);
 SIFT3D_AMD_API int sift3d_amd_sharded_info(const sift3d_amd_sharded *, int *num_octaves, int *o_shard,
                                            int *halo);
@@ -282,6 +285,10 @@ sift3d_hip_fir(const sift3d_hip_fir_args *args, void *stream);
 SIFT3D_AMD_API int
 sift3d_hip_fir_yz_u1(const float *d_src, float *d_dst, int nx, int ny, int nz, const float *taps,
                      int width, int n_glob, int off, int z_lo, int z_hi, void *stream);
+/* 1 when sift3d_hip_fir_yz_u1 covers the configuration (it returns 1 = "not covered" otherwise); for
+ * callers that must know before they launch. */
+SIFT3D_AMD_API int sift3d_hip_fir_yz_u1_covers(const float *d_src, const float *d_dst, int nx, int ny,
+                                               int width, int n_glob);
 
 /* im_subtract (imutil.c:719-739) fused with the dogmax scan of detect_extrema
  * (sift.c:821-826): dst = a - b and *d_absmax = max(*d_absmax, max|dst|).

@@ -2,7 +2,7 @@
 
   sift3d_amd.api      Python mirror of the reference C API (ctypes over libsift3d_amd.so)
   sift3d_amd.hip      device-level stage ABI on torch tensors
-  sift3d_amd.sharded  Z-slab multi-GPU driver (torch.distributed / RCCL)
+  sift3d_amd.sharded_c  bindings of the C Z-slab multi-GPU driver (sift3d_amd_sharded_*, RCCL)
 
 The compute lives in sift3d_amd/csrc (HIP kernels + C host code); nothing here computes.
 """

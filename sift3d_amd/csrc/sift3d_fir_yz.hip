@@ -230,6 +230,16 @@ static void launch_fir_yz(const FirParams &P, const FirTaps &T, const EdgeTab &E
 
 extern "C" {
 
+// does sift3d_hip_fir_yz_u1 cover this configuration?  (one predicate for the kernel's own check and
+// for callers that have to know BEFORE they launch -- the slab driver enqueues the halo exchange of
+// the z pass's input, which is another buffer when the passes run separately)
+int sift3d_hip_fir_yz_u1_covers(const float *d_src, const float *d_dst, int nx, int ny, int width, int n_glob)
+{
+    const int hw = width / 2;
+    return !(hw < 1 || hw > 8 || (nx & 3) || ((((uintptr_t)d_src | (uintptr_t)d_dst) & 15) != 0) ||
+             ny < 2 * hw + 2 || n_glob < 2 * hw + 2 || n_glob >= (1 << 22) || ny >= (1 << 22));
+}
+
 int sift3d_hip_fir_yz_u1(const float *d_src, float *d_dst, int nx, int ny, int nz, const float *taps,
                          int width, int n_glob, int off, int z_lo, int z_hi, void *stream)
 {
@@ -242,8 +252,7 @@ int sift3d_hip_fir_yz_u1(const float *d_src, float *d_dst, int nx, int ny, int n
         return SIFT3D_FAILURE;
     }
     // not covered -> the caller runs the y and z passes separately
-    if (hw < 1 || hw > 8 || (nx & 3) || ((((uintptr_t)d_src | (uintptr_t)d_dst) & 15) != 0) ||
-        ny < 2 * hw + 2 || n_glob < 2 * hw + 2 || n_glob >= (1 << 22) || ny >= (1 << 22))
+    if (!sift3d_hip_fir_yz_u1_covers(d_src, d_dst, nx, ny, width, n_glob))
         return 1;
     if (z_hi <= z_lo)
         return SIFT3D_SUCCESS;

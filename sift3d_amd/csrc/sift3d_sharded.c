@@ -26,16 +26,19 @@
  * exchange is enqueued on a second stream as soon as the x pass has finished, the interior planes
  * (which need no halo) are filtered meanwhile, the 2 * reach boundary planes afterwards.
  *
- * Scope: the default configuration of the detector (three keypoint levels per octave, 8-neighbour
- * extrema, rows of whole quads); sift3d_amd_sharded_create refuses anything else.
- * sift3d_amd/sharded.py is the same orchestration in Python (any configuration; it also runs on
- * the CPU oracle backend in the gloo tests). */
+ * Scope: everything the drop-in API accepts -- any number of keypoint levels per octave
+ * (sift.c:527-533), the cuboid extrema neighbourhood (sift.c:24, 761-796), any volume size (the
+ * reference halves dimensions with integer division, imutil.c:1545-1547, so rows that are not
+ * whole quads are a normal case).  Octaves the DoG-free extrema sweep does not cover store their
+ * DoG levels and take sift3d_hip_extrema_mode, exactly as the single-GPU path does
+ * (sift3d_host.c: detect_on_device).  tests/sharded_py.py is the same orchestration in Python on a
+ * pluggable compute backend: test infrastructure for the gloo runs on the CPU oracle. */
 
 #include <dlfcn.h>
 
-#define SH_NGL 6
-#define SH_NDL 5
-#define SH_K 3
+#define SH_MAX_K 8                  /* keypoint levels per octave (as sift3d_host.c) */
+#define SH_MAX_NGL (SH_MAX_K + 3)
+#define SH_MAX_NDL (SH_MAX_K + 2)
 #define SH_MAX_OCT 32
 #define SH_MAX_WORLD 64
 
@@ -62,20 +65,24 @@ struct sift3d_amd_sharded {
     int dims[SH_MAX_OCT][3];
     int b0[SH_MAX_WORLD + 1];
     int bounds[SH_MAX_OCT][SH_MAX_WORLD + 1];
-    int win_reach[SH_NGL];
-    filter_t filt[SH_NGL];
+    int K, ngl, ndl;                 /* keypoint / Gaussian / DoG levels per octave */
+    int cuboid;
+    int dog_free[SH_MAX_OCT];        /* octave takes the DoG-free sweep (no stored DoG levels) */
+    int win_reach[SH_MAX_NGL];
+    filter_t filt[SH_MAX_NGL];
     /* device state */
-    void *stream, *comm_stream, *ev_x, *ev_halo, *ev0, *ev1;
+    void *stream, *comm_stream, *ev_x, *ev_halo, *ev0, *ev1, *ev2, *ev3, *ev4;
     void *oct_stream, *ev_fork, *ev_join;   /* extrema sweeps of octaves >= 1 beside octave 0's */
     void *d_work2;                          /* their work areas, kept until the ordered emission */
     size_t work2_off[SH_MAX_OCT], work2_sz[SH_MAX_OCT], work2_bytes;
-    sh_level G[SH_MAX_OCT][SH_NGL];
+    sh_level G[SH_MAX_OCT][SH_MAX_NGL];
+    float *D[SH_MAX_OCT][SH_MAX_NDL];   /* stored DoG levels (geometry of G[o][*]), where needed */
     sh_level tmp_a, tmp_b, im;       /* scratch levels of octave 0 size (re-described per octave) */
     float *d_tmp_a, *d_tmp_b, *d_im, *d_raw, *d_stage;
     size_t tmp_elems, stage_elems;
     int in_z0, in_z1;
     float *d_scalars;                /* [0] input max, [1] candidate count, [8 + 5 o + k] dogmax */
-    sift3d_hip_level h_levels[SH_MAX_OCT * SH_NGL], *d_levels;
+    sift3d_hip_level h_levels[SH_MAX_OCT * SH_MAX_NGL], *d_levels;
     void *d_work;
     size_t work_bytes;
     float *d_wlut;
@@ -90,19 +97,23 @@ struct sift3d_amd_sharded {
     sift3d_hip_kp *d_kp, *h_kp;
     uint32_t kp_cap;
     int ncand;
-    double t[4];                     /* pyramid device seconds, detect wall, describe wall, - */
+    /* [0] pyramid (device s)  [1] detect wall  [2] describe wall  [3] DoG maxima + extrema (device s,
+     * incl. the all-reduce)  [4] wait for the window halos + orientation (device s)  [5] gathers +
+     * global list (host s)  [6] input scaling (device s, incl. the all-reduce) */
+    double t[8];
+    double t_gather0;
 };
 
 static int sh_sharded(const sift3d_amd_sharded *S, int o) { return o < S->o_shard; }
 
 static double sh_scale(const sift3d_amd_sharded *S, int o, int s)
 {
-    return S->sigma0 * pow(2.0, o + (double)s / SH_K);           /* imutil.c:1578-1579 */
+    return S->sigma0 * pow(2.0, o + (double)s / S->K);           /* imutil.c:1578-1579 */
 }
 
 static size_t sh_plane(const sift3d_amd_sharded *S, int o) { return (size_t)S->dims[o][0] * S->dims[o][1]; }
 
-/* ---- geometry (sharded.py: Geometry) ------------------------------------------------------ */
+/* ---- geometry ------------------------------------------------------------------------------ */
 static int sh_geometry(sift3d_amd_sharded *S)
 {
     int mn = S->nx < S->ny ? S->nx : S->ny, last, o, r, d[3], align, min_slab;
@@ -160,10 +171,13 @@ void sift3d_amd_sharded_free(sift3d_amd_sharded *S)
         sift3d_hip_stream_sync(S->comm_stream);
     if (S->oct_stream)
         sift3d_hip_stream_sync(S->oct_stream);
-    for (o = 0; o < SH_MAX_OCT; o++)
-        for (s = 0; s < SH_NGL; s++)
+    for (o = 0; o < SH_MAX_OCT; o++) {
+        for (s = 0; s < SH_MAX_NGL; s++)
             sh_free_level(&S->G[o][s]);
-    for (s = 0; s < SH_NGL; s++)
+        for (s = 0; s < SH_MAX_NDL; s++)
+            sift3d_hip_free(S->D[o][s]);
+    }
+    for (s = 0; s < SH_MAX_NGL; s++)
         free(S->filt[s].taps);
     sift3d_hip_free(S->d_tmp_a); sift3d_hip_free(S->d_tmp_b); sift3d_hip_free(S->d_im);
     sift3d_hip_free(S->d_raw); sift3d_hip_free(S->d_stage); sift3d_hip_free(S->d_scalars);
@@ -175,6 +189,7 @@ void sift3d_amd_sharded_free(sift3d_amd_sharded *S)
     sift3d_hip_host_free(S->h_xchg); sift3d_hip_host_free(S->h_kp);
     sift3d_hip_event_destroy(S->ev_x); sift3d_hip_event_destroy(S->ev_halo);
     sift3d_hip_event_destroy(S->ev0); sift3d_hip_event_destroy(S->ev1);
+    sift3d_hip_event_destroy(S->ev2); sift3d_hip_event_destroy(S->ev3); sift3d_hip_event_destroy(S->ev4);
     sift3d_hip_event_destroy(S->ev_fork); sift3d_hip_event_destroy(S->ev_join);
     sift3d_hip_stream_destroy(S->oct_stream);
     sift3d_hip_stream_destroy(S->comm_stream);
@@ -198,18 +213,17 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
         ERR("sift3d_amd: no HIP device is available; this library has no CPU path \n");
         return NULL;
     }
-    if (params && (params->num_kp_levels != SH_K || params->cuboid_extrema)) {
-        ERR("sift3d_amd_sharded: only the default configuration (3 keypoint levels per octave, "
-            "8-neighbour extrema) is supported by the C slab driver \n");
-        return NULL;
-    }
-    if (nx & 3) {
-        ERR("sift3d_amd_sharded: rows must be whole quads (nx %% 4 == 0) \n");
+    if (params && (params->num_kp_levels < 1 || params->num_kp_levels > SH_MAX_K)) {
+        ERR("sift3d_amd_sharded: 1 to %d keypoint levels per octave are supported \n", SH_MAX_K);
         return NULL;
     }
     S = (sift3d_amd_sharded *)calloc(1, sizeof(*S));
     if (!S)
         return NULL;
+    S->K = params ? params->num_kp_levels : 3;
+    S->ngl = S->K + 3;                                             /* sift.c:434-437 */
+    S->ndl = S->K + 2;
+    S->cuboid = params ? params->cuboid_extrema : 0;
     S->T = *T;
     S->rank = T->rank; S->world = T->world;
     S->peak_thresh = params ? params->peak_thresh : peak_thresh_default;
@@ -218,14 +232,14 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
     S->sigma0 = params ? params->sigma0 : sigma0_default;
     S->units[0] = ux; S->units[1] = uy; S->units[2] = uz;
     S->nx = nx; S->ny = ny; S->nz = nz;
-    if (S->sigma0 * pow(2.0, -1.0 / SH_K) < S->sigma_n) {          /* imutil.c:1582-1588 */
+    if (S->sigma0 * pow(2.0, -1.0 / S->K) < S->sigma_n) {          /* imutil.c:1582-1588 */
         ERR("set_scales_Pyramid: sigma_n too large for these settings. \n");
         goto fail;
     }
     /* filter bank (make_gss, imutil.c:1360-1409) */
-    for (i = 0; i < SH_NGL; i++) {
-        const double s_cur = i == 0 ? S->sigma_n : S->sigma0 * pow(2.0, (double)(i - 2) / SH_K);
-        const double s_next = S->sigma0 * pow(2.0, (double)(i - 1) / SH_K);
+    for (i = 0; i < S->ngl; i++) {
+        const double s_cur = i == 0 ? S->sigma_n : S->sigma0 * pow(2.0, (double)(i - 2) / S->K);
+        const double s_next = S->sigma0 * pow(2.0, (double)(i - 1) / S->K);
         if (gauss_filter(&S->filt[i], sqrt(s_next * s_next - s_cur * s_cur)) ||
             S->filt[i].width > SIFT3D_HIP_MAX_TAPS)
             goto fail;
@@ -235,13 +249,13 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
     /* halo planes a slab needs from its neighbours, in LEVEL planes (the same in every octave):
      * descriptor window of Gaussian level s: 14.1422 * sigma0 * 2^((s-1)/K) / uz + 2
      * (sift.c:1453-1454); z pass: ceil(hw * unit_factor) + 1 (imutil.c:756-757) */
-    for (s = 0; s < SH_NGL; s++)
-        S->win_reach[s] = (s >= 1 && s <= SH_K)
-                              ? (int)ceil(14.1422 * S->sigma0 * pow(2.0, (double)(s - 1) / SH_K) / uz) + 2
+    for (s = 0; s < S->ngl; s++)
+        S->win_reach[s] = (s >= 1 && s <= S->K)
+                              ? (int)ceil(14.1422 * S->sigma0 * pow(2.0, (double)(s - 1) / S->K) / uz) + 2
                               : 1;
     blur_reach = (int)ceil((double)hw_max * (double)(float)(1.0 / uz)) + 1;
     S->halo = blur_reach;
-    for (s = 0; s < SH_NGL; s++)
+    for (s = 0; s < S->ngl; s++)
         if (S->win_reach[s] > S->halo)
             S->halo = S->win_reach[s];
     if (S->halo > 500) {
@@ -250,14 +264,15 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
     }
     if (sh_geometry(S))
         goto fail;
+    /* the DoG-free sweep covers the default level count and 8-neighbour test on rows of whole quads
+     * (sift3d_hip_dogmax_stack / sift3d_hip_extrema_gauss6); other octaves store their DoG levels */
     for (o = 0; o < S->num_octaves; o++)
-        if (S->dims[o][0] & 3) {
-            ERR("sift3d_amd_sharded: rows of octave %d are not whole quads (nx = %d) \n", o, S->dims[o][0]);
-            goto fail;
-        }
+        S->dog_free[o] = !S->cuboid && S->ngl == 6 && (S->dims[o][0] & 3) == 0;
     if (!(S->stream = sift3d_hip_stream_create()) || !(S->comm_stream = sift3d_hip_stream_create()) ||
         !(S->ev_x = sift3d_hip_event_create()) || !(S->ev_halo = sift3d_hip_event_create()) ||
         !(S->ev0 = sift3d_hip_event_create()) || !(S->ev1 = sift3d_hip_event_create()) ||
+        !(S->ev2 = sift3d_hip_event_create()) || !(S->ev3 = sift3d_hip_event_create()) ||
+        !(S->ev4 = sift3d_hip_event_create()) ||
         !(S->oct_stream = sift3d_hip_stream_create_high()) || !(S->ev_fork = sift3d_hip_event_create()) ||
         !(S->ev_join = sift3d_hip_event_create()) || upload_mesh())
         goto fail;
@@ -267,19 +282,26 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
         const int z0 = S->bounds[o][S->rank], z1 = S->bounds[o][S->rank + 1];
         const int off = sh_sharded(S, o) ? (z0 - S->halo > 0 ? z0 - S->halo : 0) : 0;
         const int hi = sh_sharded(S, o) ? (z1 + S->halo < nzo ? z1 + S->halo : nzo) : nzo;
-        const size_t w = sift3d_hip_extrema_work_bytes(S->dims[o][0], S->dims[o][1], hi - off, SH_K);
+        const size_t w = sift3d_hip_extrema_work_bytes(S->dims[o][0], S->dims[o][1], hi - off, S->K);
         work = w > work ? w : work;
         if (o >= 1) {
             S->work2_off[o] = S->work2_bytes;
             S->work2_sz[o] = w;
             S->work2_bytes += (w + 255) & ~(size_t)255;
         }
-        for (s = 0; s < SH_NGL; s++) {
+        /* (all levels of an octave share one geometry -- the fused sweeps take them as a stack; only
+         * the keypoint levels 1..K USE the full window halo, the others a blur's or the extrema
+         * test's reach) */
+        for (s = 0; s < S->ngl; s++) {
             sh_level *L = &S->G[o][s];
             L->off = off; L->nloc = hi - off; L->z0 = z0; L->z1 = z1; L->nz_glob = nzo;
             if (!(L->t = (float *)sift3d_hip_malloc(sh_plane(S, o) * (size_t)L->nloc * sizeof(float))))
                 goto fail;
         }
+        if (!S->dog_free[o])
+            for (s = 0; s < S->ndl; s++)
+                if (!(S->D[o][s] = (float *)sift3d_hip_malloc(sh_plane(S, o) * (size_t)(hi - off) * sizeof(float))))
+                    goto fail;
     }
     n0 = sh_plane(S, 0) * (size_t)S->G[0][0].nloc;
     S->tmp_elems = n0;
@@ -308,21 +330,21 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
         S->stage_elems = stage;
         S->d_stage = (float *)sift3d_hip_malloc(stage * sizeof(float));
     }
-    S->d_scalars = (float *)sift3d_hip_malloc(sizeof(float) * (8 + SH_NDL * SH_MAX_OCT));
-    S->d_levels = (sift3d_hip_level *)sift3d_hip_malloc(sizeof(sift3d_hip_level) * SH_MAX_OCT * SH_NGL);
+    S->d_scalars = (float *)sift3d_hip_malloc(sizeof(float) * (8 + SH_MAX_NDL * SH_MAX_OCT));
+    S->d_levels = (sift3d_hip_level *)sift3d_hip_malloc(sizeof(sift3d_hip_level) * SH_MAX_OCT * SH_MAX_NGL);
     S->d_work = sift3d_hip_malloc(work);
     S->work_bytes = work;
     if (S->work2_bytes && !(S->d_work2 = sift3d_hip_malloc(S->work2_bytes)))
         goto fail;
     S->d_wlut = (float *)sift3d_hip_malloc(sizeof(float) *
-                                           sift3d_hip_describe_wlut_floats(S->num_octaves * SH_NGL));
+                                           sift3d_hip_describe_wlut_floats(S->num_octaves * S->ngl));
     if (!S->d_wlut || !S->d_tmp_a || !S->d_tmp_b || !S->d_im || !S->d_raw || !S->d_stage || !S->d_scalars ||
         !S->d_levels || !S->d_work)
         goto fail;
     /* level table (window kernels) */
     for (o = 0; o < S->num_octaves; o++)
-        for (s = 0; s < SH_NGL; s++) {
-            sift3d_hip_level *L = &S->h_levels[o * SH_NGL + s];
+        for (s = 0; s < S->ngl; s++) {
+            sift3d_hip_level *L = &S->h_levels[o * S->ngl + s];
             L->data = S->G[o][s].t;
             L->nx = S->dims[o][0]; L->ny = S->dims[o][1]; L->nz = S->G[o][s].nloc;
             L->z_off = S->G[o][s].off;
@@ -334,7 +356,7 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
             L->sd = sh_scale(S, o, s - 1);
         }
     if (sift3d_hip_memcpy_h2d(S->d_levels, S->h_levels,
-                              sizeof(sift3d_hip_level) * (size_t)S->num_octaves * SH_NGL, S->stream) ||
+                              sizeof(sift3d_hip_level) * (size_t)S->num_octaves * S->ngl, S->stream) ||
         sift3d_hip_stream_sync(S->stream))
         goto fail;
     return S;
@@ -364,7 +386,7 @@ int sift3d_amd_sharded_synth(sift3d_amd_sharded *S, uint64_t seed)
 }
 
 int sift3d_amd_sharded_num_candidates(const sift3d_amd_sharded *S) { return S ? S->ncand : -1; }
-const double *sift3d_amd_sharded_timings(const sift3d_amd_sharded *S) { return S->t; }
+const double *sift3d_amd_sharded_timings(const sift3d_amd_sharded *S) { return S ? S->t : NULL; }
 int sift3d_amd_sharded_info(const sift3d_amd_sharded *S, int *num_octaves, int *o_shard, int *halo)
 {
     if (!S)
@@ -434,7 +456,7 @@ static int sh_blur(sift3d_amd_sharded *S, int o, const float *src, const sh_leve
     int fused, ia, ib, rc;
     if (sh_fir(S, src, S->d_tmp_a, o, Lg->nloc, 0, f, ufx, 0, a, b, S->stream))
         return SIFT3D_FAILURE;
-    fused = ufy == 1.0f && ufz == 1.0f && hw >= 1 && hw <= 8 && ny >= 2 * hw + 2 && nzo >= 2 * hw + 2;
+    fused = ufy == 1.0f && ufz == 1.0f && sift3d_hip_fir_yz_u1_covers(S->d_tmp_a, dst, nx, ny, f->width, nzo);
     zin = S->d_tmp_a;
     if (!fused) {
         if (sh_fir(S, S->d_tmp_a, S->d_tmp_b, o, Lg->nloc, 1, f, ufy, 0, a, b, S->stream))
@@ -531,18 +553,21 @@ static int sh_ensure_cand(sift3d_amd_sharded *S, uint32_t cap)
 int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
 {
     const double t_start = now_s();
-    const int nkey = S->num_octaves * SH_K;
     uint32_t count = 0;
-    int o, s, r, i, k, attempt;
+    int o, s, r, i, k, attempt, nkey, all_free = 1;
     if (!S || !kp)
         return SIFT3D_FAILURE;
+    nkey = S->num_octaves * S->K;
+    for (o = 0; o < S->num_octaves; o++)
+        all_free = all_free && S->dog_free[o];
 
     /* set_im_SIFT3D: scale by the GLOBAL max|v| (sift.c:645-649) */
+    sift3d_hip_event_record(S->ev4, S->stream);
     {
         const size_t n_in = sh_plane(S, 0) * (size_t)(S->in_z1 - S->in_z0);
         const sh_level *L0 = &S->G[0][0];
         const int a = sh_sharded(S, 0) ? L0->z0 - L0->off : 0;
-        if (sift3d_hip_memset(S->d_scalars, 0, sizeof(float) * (8 + SH_NDL * SH_MAX_OCT), S->stream) ||
+        if (sift3d_hip_memset(S->d_scalars, 0, sizeof(float) * (8 + SH_MAX_NDL * SH_MAX_OCT), S->stream) ||
             sift3d_hip_absmax(S->d_raw, n_in, S->d_scalars, S->stream))
             return SIFT3D_FAILURE;
         if (S->world > 1 && S->T.allreduce_max(S->T.ctx, S->d_scalars, 1, S->stream))
@@ -555,12 +580,12 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
     for (o = 0; o < S->num_octaves; o++) {
         if (o == 0 && sh_blur(S, 0, S->d_im, &S->G[0][0], S->G[0][0].t, &S->filt[0]))
             return SIFT3D_FAILURE;
-        for (s = 1; s < SH_NGL; s++)
+        for (s = 1; s < S->ngl; s++)
             if (sh_blur(S, o, S->G[o][s - 1].t, &S->G[o][s], S->G[o][s].t, &S->filt[s]))
                 return SIFT3D_FAILURE;
         if (o != S->num_octaves - 1) {
-            /* level max(s_end - 2, first_level) = Gaussian index 3, sift.c:696-704 */
-            const sh_level *src = &S->G[o][3];
+            /* level max(s_end - 2, first_level) = Gaussian index K, sift.c:696-704 */
+            const sh_level *src = &S->G[o][S->K];
             sh_level *dst = &S->G[o + 1][0];
             const int mx = S->dims[o + 1][0], my = S->dims[o + 1][1], mzg = S->dims[o + 1][2];
             const size_t pl_s = sh_plane(S, o), pl_d = sh_plane(S, o + 1);
@@ -609,39 +634,65 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
     }
     sift3d_hip_event_record(S->ev1, S->stream);
 
+    /* The nearest halo plane of every level of the sharded octaves: the extrema test looks one plane
+     * past the slab, and stored DoG levels are formed on it */
+    for (o = 0; o < S->o_shard; o++)
+        for (s = 0; s < S->ngl; s++)
+            if (sh_halo_range(S, S->G[o][s].t, &S->G[o][s], sh_plane(S, o), 0, 1, S->stream))
+                return SIFT3D_FAILURE;
+
     /* dogmax (sift.c:821-826) of every octave on the owned planes (every plane is owned by some
-     * rank), one all-reduce for all of them; no DoG level is stored */
+     * rank), one all-reduce for all of them.  Octaves of the DoG-free sweep store no DoG level; the
+     * others form theirs (build_dog, sift.c:713-732) on the owned planes and one plane around them
+     * -- the neighbours' planes are theirs to count, but a maximum does not mind a plane twice. */
     for (o = 0; o < S->num_octaves; o++) {
         const sh_level *L = &S->G[o][0];
+        const size_t plane = sh_plane(S, o);
         const int lo = sh_sharded(S, o) ? L->z0 - L->off : 0;
         const int hi = sh_sharded(S, o) ? L->z1 - L->off : L->nloc;
-        const float *g[SH_NGL];
-        for (s = 0; s < SH_NGL; s++)
-            g[s] = S->G[o][s].t + (size_t)lo * sh_plane(S, o);
-        if (hi > lo && sift3d_hip_dogmax_stack(g, SH_NGL, (size_t)(hi - lo) * sh_plane(S, o),
-                                               S->d_scalars + 8 + SH_NDL * o, S->stream) != SIFT3D_SUCCESS)
-            return SIFT3D_FAILURE;
+        const float *g[SH_MAX_NGL];
+        if (S->dog_free[o]) {
+            for (s = 0; s < S->ngl; s++)
+                g[s] = S->G[o][s].t + (size_t)lo * plane;
+            if (hi > lo && sift3d_hip_dogmax_stack(g, S->ngl, (size_t)(hi - lo) * plane,
+                                                   S->d_scalars + 8 + S->ndl * o, S->stream) != SIFT3D_SUCCESS)
+                return SIFT3D_FAILURE;
+        } else {
+            const int lo2 = lo > 0 ? lo - 1 : 0, hi2 = hi < L->nloc ? hi + 1 : L->nloc;
+            const size_t n2 = (size_t)(hi2 - lo2) * plane;
+            float *dd[SH_MAX_NDL];
+            int rc;
+            if (hi <= lo)
+                continue;
+            for (s = 0; s < S->ngl; s++)
+                g[s] = S->G[o][s].t + (size_t)lo2 * plane;
+            for (s = 0; s < S->ndl; s++)
+                dd[s] = S->D[o][s] + (size_t)lo2 * plane;
+            rc = sift3d_hip_dog_stack(g, dd, S->ngl, n2, S->d_scalars + 8 + S->ndl * o, S->stream);
+            if (rc == 1) {
+                for (s = 0; s < S->ndl; s++)
+                    if (sift3d_hip_subtract_absmax(g[s], g[s + 1], dd[s], n2,
+                                                   S->d_scalars + 8 + S->ndl * o + s, S->stream))
+                        return SIFT3D_FAILURE;
+            } else if (rc != SIFT3D_SUCCESS) {
+                return SIFT3D_FAILURE;
+            }
+        }
     }
     if (S->world > 1 &&
-        S->T.allreduce_max(S->T.ctx, S->d_scalars + 8, SH_NDL * S->num_octaves, S->stream))
+        S->T.allreduce_max(S->T.ctx, S->d_scalars + 8, S->ndl * S->num_octaves, S->stream))
         return SIFT3D_FAILURE;
 
-    /* Halos of the sharded octaves.  The extrema sweep looks one plane past the slab; the windows
-     * of the orientation and descriptor kernels reach win_reach[s] planes.  The nearest plane is
-     * exchanged here; the rest -- the largest exchange of a step -- travels on the communication
-     * stream WHILE the extrema are found, and is awaited before the orientation kernel.  (No
-     * collective is issued on the compute stream in between: one communicator, one order.) */
-    for (o = 0; o < S->o_shard; o++)
-        for (s = 0; s < SH_NGL; s++)
-            if (sh_halo_range(S, S->G[o][s].t, &S->G[o][s], sh_plane(S, o), 0,
-                              S->win_reach[s] < 1 ? S->win_reach[s] : 1, S->stream))
-                return SIFT3D_FAILURE;
+    /* The windows of the orientation and descriptor kernels reach win_reach[s] planes into the
+     * neighbours' slabs: the largest exchange of a step.  It travels on the communication stream
+     * WHILE the extrema are found, and is awaited before the orientation kernel.  (No collective is
+     * issued on the compute stream in between: one communicator, one order.) */
     if (S->world > 1 && S->o_shard > 0) {
         if (sift3d_hip_event_record(S->ev_x, S->stream) ||
             sift3d_hip_stream_wait_event(S->comm_stream, S->ev_x))
             return SIFT3D_FAILURE;
         for (o = 0; o < S->o_shard; o++)
-            for (s = 0; s < SH_NGL; s++)
+            for (s = 0; s < S->ngl; s++)
                 if (sh_halo_range(S, S->G[o][s].t, &S->G[o][s], sh_plane(S, o), 1, S->win_reach[s],
                                   S->comm_stream))
                     return SIFT3D_FAILURE;
@@ -654,43 +705,59 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
     if (sh_ensure_cand(S, S->cand_cap ? S->cand_cap : (1u << 18)))
         return SIFT3D_FAILURE;
     for (attempt = 0; attempt < 2; attempt++) {
+        /* with every octave on the DoG-free sweep: the sweeps of octaves >= 1 (short launches) beside
+         * octave 0's on a second stream, then scan + emission in octave order
+         * (sift3d_hip_extrema_gauss6_phase); otherwise octave by octave */
+        const int side = all_free && S->num_octaves > 1 && S->d_work2 != NULL;
+        int phase;
         if (sift3d_hip_memset(S->d_scalars + 1, 0, sizeof(uint32_t), S->stream))
             return SIFT3D_FAILURE;
-        /* the sweeps of octaves >= 1 (short launches) beside octave 0's on a second stream, then scan
-         * + emission in octave order (sift3d_hip_extrema_gauss6_phase) */
-        {
-            const int side = S->num_octaves > 1 && S->d_work2 != NULL;
-            int phase;
-            if (side && (sift3d_hip_event_record(S->ev_fork, S->stream) ||
-                         sift3d_hip_stream_wait_event(S->oct_stream, S->ev_fork)))
-                return SIFT3D_FAILURE;
-            for (phase = side ? 1 : 0; phase <= (side ? 2 : 0); phase++) {
-                for (o = 0; o < S->num_octaves; o++) {
-                    const sh_level *L = &S->G[o][0];
-                    const int nzo = S->dims[o][2];
-                    const int zl = (L->z0 > 1 ? L->z0 : 1) - L->off;
-                    int zh = (L->z1 < nzo - 1 ? L->z1 : nzo - 1) - L->off;
-                    const float *g[SH_NGL];
-                    void *wk = side && o > 0 ? (void *)((char *)S->d_work2 + S->work2_off[o]) : S->d_work;
-                    const size_t wb = side && o > 0 ? S->work2_sz[o] : S->work_bytes;
-                    if (zh < zl)
-                        zh = zl;
-                    for (s = 0; s < SH_NGL; s++)
-                        g[s] = S->G[o][s].t;
-                    if (L->nloc < 3 || zh <= zl)
-                        continue;                            /* no interior plane on this rank */
-                    if (sift3d_hip_extrema_gauss6_phase(g, S->d_scalars + 8 + SH_NDL * o, S->dims[o][0],
-                                                        S->dims[o][1], L->nloc, zl, zh, o * SH_NGL + 1,
+        if (side && (sift3d_hip_event_record(S->ev_fork, S->stream) ||
+                     sift3d_hip_stream_wait_event(S->oct_stream, S->ev_fork)))
+            return SIFT3D_FAILURE;
+        for (phase = side ? 1 : 0; phase <= (side ? 2 : 0); phase++) {
+            for (o = 0; o < S->num_octaves; o++) {
+                const sh_level *L = &S->G[o][0];
+                const int nzo = S->dims[o][2];
+                const int zl = (L->z0 > 1 ? L->z0 : 1) - L->off;
+                int zh = (L->z1 < nzo - 1 ? L->z1 : nzo - 1) - L->off;
+                const float *g[SH_MAX_NGL];
+                void *wk = side && o > 0 ? (void *)((char *)S->d_work2 + S->work2_off[o]) : S->d_work;
+                const size_t wb = side && o > 0 ? S->work2_sz[o] : S->work_bytes;
+                if (zh < zl)
+                    zh = zl;
+                for (s = 0; s < S->ngl; s++)
+                    g[s] = S->G[o][s].t;
+                if (L->nloc < 3 || zh <= zl)
+                    continue;                            /* no interior plane on this rank */
+                if (S->dog_free[o]) {
+                    if (sift3d_hip_extrema_gauss6_phase(g, S->d_scalars + 8 + S->ndl * o, S->dims[o][0],
+                                                        S->dims[o][1], L->nloc, zl, zh, o * S->ngl + 1,
                                                         S->peak_thresh, S->d_cand, S->cand_cap,
                                                         (uint32_t *)(S->d_scalars + 1), wk, wb,
                                                         phase == 1 && o > 0 ? S->oct_stream : S->stream,
                                                         phase) != SIFT3D_SUCCESS)
                         return SIFT3D_FAILURE;
+                } else {
+                    sift3d_hip_extrema_level lv[SH_MAX_K];
+                    for (s = 0; s < S->K; s++) {
+                        lv[s].prev = S->D[o][s];
+                        lv[s].cur = S->D[o][s + 1];
+                        lv[s].next = S->D[o][s + 2];
+                        lv[s].d_absmax = S->d_scalars + 8 + S->ndl * o + s + 1;
+                        lv[s].z_lo = zl;
+                        lv[s].z_hi = zh;
+                        lv[s].tag = o * S->ngl + s + 1;          /* Gaussian level (o, s) of the table */
+                    }
+                    if (sift3d_hip_extrema_mode(lv, S->K, S->dims[o][0], S->dims[o][1], L->nloc, S->peak_thresh,
+                                                S->cuboid, S->d_cand, S->cand_cap,
+                                                (uint32_t *)(S->d_scalars + 1), wk, wb, S->stream))
+                        return SIFT3D_FAILURE;
                 }
-                if (phase == 1 && (sift3d_hip_event_record(S->ev_join, S->oct_stream) ||
-                                   sift3d_hip_stream_wait_event(S->stream, S->ev_join)))
-                    return SIFT3D_FAILURE;
             }
+            if (phase == 1 && (sift3d_hip_event_record(S->ev_join, S->oct_stream) ||
+                               sift3d_hip_stream_wait_event(S->stream, S->ev_join)))
+                return SIFT3D_FAILURE;
         }
         if (sift3d_hip_memcpy_d2h(&count, S->d_scalars + 1, sizeof(count), S->stream) ||
             sift3d_hip_stream_sync(S->stream))
@@ -700,10 +767,11 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
         if (sh_ensure_cand(S, count + count / 4 + 1024))
             return SIFT3D_FAILURE;
     }
+    sift3d_hip_event_record(S->ev2, S->stream);
     if (S->world > 1 && S->o_shard > 0 && sift3d_hip_stream_wait_event(S->stream, S->ev_halo))
         return SIFT3D_FAILURE;                           /* the window halos have arrived */
     if (count) {
-        const size_t need = sift3d_hip_orient_tab_bytes(S->num_octaves * SH_NGL, S->cand_cap);
+        const size_t need = sift3d_hip_orient_tab_bytes(S->num_octaves * S->ngl, S->cand_cap);
         if (need > S->otab_bytes) {
             sift3d_hip_free(S->d_otab);
             S->otab_bytes = 0;
@@ -713,15 +781,17 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
                 return SIFT3D_FAILURE;
             S->otab_bytes = need;
         }
-        if (sift3d_hip_orient_tab(S->d_levels, S->num_octaves * SH_NGL, S->d_cand, count, S->corner_thresh,
+        if (sift3d_hip_orient_tab(S->d_levels, S->num_octaves * S->ngl, S->d_cand, count, S->corner_thresh,
                                   S->d_R, S->d_keep, S->d_otab, S->cand_cap, S->stream) ||
             sift3d_hip_memcpy_d2h(S->h_cand, S->d_cand, sizeof(sift3d_hip_cand) * (size_t)count, S->stream) ||
             sift3d_hip_memcpy_d2h(S->h_R, S->d_R, sizeof(float) * 9 * (size_t)count, S->stream) ||
             sift3d_hip_memcpy_d2h(S->h_keep, S->d_keep, sizeof(int32_t) * (size_t)count, S->stream))
             return SIFT3D_FAILURE;
     }
+    sift3d_hip_event_record(S->ev3, S->stream);
     if (sift3d_hip_stream_sync(S->stream))
         return SIFT3D_FAILURE;
+    S->t_gather0 = now_s();
 
     /* Exchange (all-gather): per-(o,s) counts, the candidates' |DoG| values and the
      * ORIENTED keypoints only.  Global order: (o, s) major, then ranks in slab order (their z
@@ -737,7 +807,7 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
             return SIFT3D_FAILURE;
         for (i = 0; i < (int)count; i++) {
             const int tag = S->h_cand[i].tag;
-            const int key = (tag / SH_NGL) * SH_K + (tag % SH_NGL - 1);
+            const int key = (tag / S->ngl) * S->K + (tag % S->ngl - 1);
             cnt[2 * key]++;
             if (S->h_keep[i]) {
                 cnt[2 * key + 1]++;
@@ -781,14 +851,14 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
         }
         for (i = 0, j = 0; i < (int)count; i++) {
             const sift3d_hip_cand *c = S->h_cand + i;
-            const int oo = c->tag / SH_NGL;
+            const int oo = c->tag / S->ngl;
             const size_t plane = sh_plane(S, oo);
             const uint32_t rem = (uint32_t)(c->idx % plane);
             vals[i] = c->val;
             if (!S->h_keep[i])
                 continue;
             recs[j].o = oo;
-            recs[j].s = c->tag % SH_NGL - 1;
+            recs[j].s = c->tag % S->ngl - 1;
             recs[j].x = (int32_t)(rem % (uint32_t)S->dims[oo][0]);
             recs[j].y = (int32_t)(rem / (uint32_t)S->dims[oo][0]);
             recs[j].z = (int32_t)(c->idx / plane) + S->G[oo][0].off;
@@ -842,6 +912,10 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
         free(recs); free(vals); free(allcnt); free(cc); free(ck);
     }
     S->t[0] = 1e-3 * sift3d_hip_event_elapsed_ms(S->ev0, S->ev1);
+    S->t[3] = 1e-3 * sift3d_hip_event_elapsed_ms(S->ev1, S->ev2);
+    S->t[4] = 1e-3 * sift3d_hip_event_elapsed_ms(S->ev2, S->ev3);
+    S->t[5] = now_s() - S->t_gather0;
+    S->t[6] = 1e-3 * sift3d_hip_event_elapsed_ms(S->ev4, S->ev0);
     S->t[1] = now_s() - t_start;
     return SIFT3D_SUCCESS;
 }
@@ -854,13 +928,13 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
                                 sift3d_descriptor_store *desc, int *own_idx, int *n_own)
 {
     const double t_start = now_s();
-    const int num = (int)kp->num;
-    int i, n = 0, sv, pos = 0;
+    int i, n = 0, sv, pos = 0, num;
     if (!S || !kp || !desc || !own_idx || !n_own)
         return SIFT3D_FAILURE;
+    num = (int)kp->num;
     for (i = 0; i < num; i++) {
         const keypoint_t *k = kp->buf + i;
-        if (k->o < 0 || k->o >= S->num_octaves || k->s < 0 || k->s >= SH_K)
+        if (k->o < 0 || k->o >= S->num_octaves || k->s < 0 || k->s >= S->K)
             return SIFT3D_FAILURE;
         if (S->world == 1 || (k->zd >= (double)S->bounds[k->o][S->rank] &&
                               k->zd < (double)S->bounds[k->o][S->rank + 1]))
@@ -896,7 +970,7 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
         S->kp_cap = cap;
     }
     /* launch order: widest windows first, each histogram to its own row */
-    for (sv = SH_K - 1; sv >= 0; sv--)
+    for (sv = S->K - 1; sv >= 0; sv--)
         for (i = 0; i < n; i++) {
             const keypoint_t *k = kp->buf + own_idx[i];
             sift3d_hip_kp *q;
@@ -905,7 +979,7 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
             q = S->h_kp + pos++;
             memcpy(q->R, k->R, sizeof(q->R));
             q->cx = (float)k->xd; q->cy = (float)k->yd; q->cz = (float)k->zd;   /* sift.c:1474-1476 */
-            q->level = k->o * SH_NGL + k->s + 1;
+            q->level = k->o * S->ngl + k->s + 1;
             q->row1 = (uint32_t)i + 1u;
             q->sd = k->sd;
         }
@@ -921,7 +995,7 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
         float *dev_view = (float *)sift3d_hip_host_device_ptr(desc->hist);
         if (!dev_view ||
             sift3d_hip_memcpy_h2d(S->d_kp, S->h_kp, sizeof(sift3d_hip_kp) * (size_t)n, S->stream) ||
-            sift3d_hip_describe_wlut(S->d_levels, S->num_octaves * SH_NGL, S->d_kp, (uint32_t)n, dev_view,
+            sift3d_hip_describe_wlut(S->d_levels, S->num_octaves * S->ngl, S->d_kp, (uint32_t)n, dev_view,
                                      S->d_wlut, S->stream) ||
             sift3d_hip_stream_sync(S->stream))
             return SIFT3D_FAILURE;

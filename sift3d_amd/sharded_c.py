@@ -2,7 +2,7 @@
 
 The orchestration of the multi-GPU run lives in C (the reference's host language); this module
 only (a) builds the transport the C driver talks through and (b) exposes the run to bench.py and
-the tests with the same methods as the Python driver (sift3d_amd.sharded.ShardedSift3D):
+the tests:
 
   * transport "rccl": the library's own RCCL communicator (send/recv, all-reduce, all-gather over
     xGMI).  The 128-byte unique id is made on rank 0 and distributed with torch.distributed --
@@ -16,7 +16,9 @@ import ctypes as C
 import numpy as np
 
 from . import api, hip
-from .sharded import KP_DTYPE
+
+KP_DTYPE = np.dtype([("R", "f4", (3, 3)), ("xd", "f8"), ("yd", "f8"), ("zd", "f8"),
+                     ("sd", "f8"), ("o", "i4"), ("s", "i4"), ("strength", "f4")])
 
 _HALO = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                     C.c_void_p)
@@ -348,3 +350,9 @@ class CShardedSift3D:
 
     def pyramid_seconds(self):
         return float(_lib().sift3d_amd_sharded_timings(self.h)[0])
+
+    def breakdown(self):
+        """Seconds of the last step by stage (this rank)."""
+        t = _lib().sift3d_amd_sharded_timings(self.h)
+        return dict(scale=t[6], pyramid=t[0], dog_extrema=t[3], halo_wait_orient=t[4], gathers=t[5],
+                    detect_wall=t[1], describe_wall=t[2])

@@ -1,6 +1,6 @@
-"""CPU compute backend for sift3d_amd.sharded -- TEST INFRASTRUCTURE ONLY.
+"""CPU compute backend for tests.sharded_py -- TEST INFRASTRUCTURE ONLY.
 
-Implements the backend interface of sift3d_amd.sharded.HipBackend with the oracle
+Implements the backend interface of tests.sharded_py.HipBackend with the oracle
 (oracle/sift3d_oracle.c) on torch CPU tensors, so that the Z-slab orchestration (slab
 geometry, halo exchange, reductions, gather order) can be exercised with gloo on machines
 without a GPU.  The product never imports this module.

@@ -1,4 +1,11 @@
-"""Z-slab multi-GPU driver: one process per GPU, torch.distributed (RCCL over xGMI).
+"""TEST INFRASTRUCTURE: the Z-slab orchestration once more in Python, on a pluggable compute backend.
+
+The product's slab driver is C (sift3d_amd/csrc/sift3d_sharded.c).  This module restates the same
+orchestration on top of a small backend interface so that the sharding LOGIC -- slab geometry, halo
+exchange, reductions, gather order -- can run with gloo on the CPU oracle (tests/cpu_backend.py) on
+machines without a GPU, and on the HIP stage ABI as a cross-check of the C driver.
+
+Z-slab multi-GPU driver: one process per GPU, torch.distributed.
 
 The volume is split along z into one contiguous slab per rank.  Everything that is local
 in z runs unchanged on the slab (x / y FIR passes, DoG, down-sampling on 2^k-aligned slab
@@ -99,7 +106,7 @@ class HipBackend:
 
     def __init__(self):
         import torch
-        from . import api, hip
+        from sift3d_amd import api, hip
         self.torch, self.hip, self.api = torch, hip, api
         hip.lib()
         if not api.device_available():
@@ -674,7 +681,7 @@ class ShardedSift3D:
         hist [n, 768]); the union over ranks covers every keypoint exactly once."""
         g, be, r = self.g, self.be, self.rank
         kp = self.kp if kp is None else kp
-        from .hip import KP_DTYPE as HKP
+        from sift3d_amd.hip import KP_DTYPE as HKP
         if self.world == 1:
             idx = np.arange(len(kp))
         else:

@@ -26,7 +26,8 @@ def _worker(rank, world, port, dims, outdir, cuboid=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from sift3d_amd import api, sharded
+    from sift3d_amd import api
+    from tests import sharded_py as sharded
 
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
@@ -75,7 +76,7 @@ def test_sharded_hip_equals_single_gpu(world, dims, cuboid):
     np.testing.assert_array_equal(covered, 1)
 
 
-def _worker_c(rank, world, port, dims, outdir):
+def _worker_c(rank, world, port, dims, outdir, det_kw=None):
     """The C slab driver (sift3d_amd_sharded_*) with host-staged gloo exchanges."""
     sys.path.insert(0, ROOT)
     import torch
@@ -88,7 +89,8 @@ def _worker_c(rank, world, port, dims, outdir):
     try:
         nx, ny, nz = dims
         vol = api.synth_lattice(dims, seed=5)
-        job = sharded_c.CShardedSift3D(nx, ny, nz, sharded_c.DistTransport())
+        det = api.Detector(**det_kw) if det_kw else None
+        job = sharded_c.CShardedSift3D(nx, ny, nz, sharded_c.DistTransport(), detector=det)
         z0, z1 = job.in_own
         job.set_local_volume(vol[z0:z1])
         job.detect()
@@ -101,21 +103,29 @@ def _worker_c(rank, world, port, dims, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dims", [(2, (64, 72, 256)), (3, (48, 48, 320)), (2, (32, 40, 48))])
-def test_c_slab_driver_equals_single_gpu(world, dims):
+@pytest.mark.parametrize("world,dims,det_kw", [
+    (2, (64, 72, 256), None), (3, (48, 48, 320), None), (2, (32, 40, 48), None),
+    # what the reference API accepts and the default sweep does not cover: rows that are not whole
+    # quads (130 -> 65 -> 32 -> 16: imutil.c:1545-1547), the cuboid neighbourhood (sift.c:24,
+    # 761-796), another level count (sift.c:527-533) -- stored DoG levels + sift3d_hip_extrema_mode
+    (2, (130, 126, 244), None), (2, (64, 72, 256), dict(cuboid_extrema=True)),
+    (2, (48, 52, 240), dict(num_kp_levels=2, sigma_n=1.0)),
+    (3, (50, 46, 330), dict(num_kp_levels=4, cuboid_extrema=True, peak_thresh=0.05))])
+def test_c_slab_driver_equals_single_gpu(world, dims, det_kw):
     """sift3d_amd_sharded_detect / _describe (host orchestration in C, exchanges through the
     transport vtable) == the single-GPU drop-in API, bit for bit: sharded octaves, the
-    sharded -> replicated transition, a volume too small to shard at all."""
+    sharded -> replicated transition, a volume too small to shard at all, and the
+    configurations that take stored DoG levels."""
     import torch
     import torch.multiprocessing as mp
     from sift3d_amd import api
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no HIP device is visible")
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker_c, args=(world, _free_port(), dims, d), nprocs=world, join=True)
+        mp.spawn(_worker_c, args=(world, _free_port(), dims, d, det_kw), nprocs=world, join=True)
         res = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(world)]
     vol = api.synth_lattice(dims, seed=5)
-    det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+    det, kp, desc = api.Detector(**(det_kw or {})), api.KeypointStore(), api.DescriptorStore()
     assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
     assert det.extract_descriptors(kp, desc) == 0
     k = kp.records()

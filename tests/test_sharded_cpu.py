@@ -1,4 +1,4 @@
-"""CPU (not gpu): the Z-slab multi-GPU orchestration (sift3d_amd/sharded.py) with gloo,
+"""CPU (not gpu): the Z-slab multi-GPU orchestration (tests/sharded_py.py, the Python restatement of the C slab driver) with gloo,
 world_size 2 and 3, on the oracle compute backend (tests/cpu_backend.py).
 
 What is under test is the sharding logic itself: slab bounds and their 2^k alignment, the
@@ -31,7 +31,7 @@ def _worker(rank, world, port, dims, outdir, cuboid=False, sigma0=1.6, units=(1.
     import torch
     import torch.distributed as dist
     from oracle import sift3d_oracle as so
-    from sift3d_amd import sharded
+    from tests import sharded_py as sharded
     from tests.cpu_backend import OracleBackend
 
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
@@ -144,7 +144,7 @@ def test_sharded_wide_windows_equal_single():
 
 
 def test_sharded_refuses_what_does_not_fit():
-    from sift3d_amd.sharded import ShardedSift3D
+    from tests.sharded_py import ShardedSift3D
     from tests.cpu_backend import OracleBackend
     with pytest.raises(ValueError):
         ShardedSift3D(32, 32, 64, None, backend=OracleBackend(), units=(1.0, 1.0, 0.0))
@@ -153,7 +153,7 @@ def test_sharded_refuses_what_does_not_fit():
 
 
 def test_geometry_alignment():
-    from sift3d_amd.sharded import Geometry, MIN_SLAB
+    from tests.sharded_py import Geometry, MIN_SLAB
     g = Geometry(512, 512, 4096, 8)
     assert g.num_octaves == 7 and g.o_shard == 4
     assert g.b0 == [512 * r for r in range(9)]
