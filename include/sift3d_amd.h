@@ -137,6 +137,21 @@ sift3d_hip_nn2(const float *d_A, int nA, const float *d_B, int nB, int dim, int 
 SIFT3D_AMD_API int
 sift3d_amd_nn_match(const sift3d_descriptor_store *a, const sift3d_descriptor_store *b,
                     double nn_thresh, int *match_ab);
+/* A matcher object: its own stream and scratch (grown on demand, reused from call to call: no
+ * allocation per match).  sift3d_amd_matcher_match is sift3d_amd_nn_match on it;
+ * sift3d_amd_matcher_seconds returns the device time of the two nearest-neighbour searches of the last
+ * match (HIP events on the matcher's stream).  Descriptor stores marked with
+ * sift3d_amd_descriptor_store_keep_device(store, 1) keep a copy of their histograms in HBM (written by
+ * sift3d_extract_descriptors beside the host array), which the matcher reads in place; other stores
+ * are uploaded per call. */
+typedef struct sift3d_amd_matcher sift3d_amd_matcher;
+SIFT3D_AMD_API sift3d_amd_matcher *sift3d_amd_make_matcher(void);
+SIFT3D_AMD_API void sift3d_amd_free_matcher(sift3d_amd_matcher *);
+SIFT3D_AMD_API int sift3d_amd_matcher_match(sift3d_amd_matcher *, const sift3d_descriptor_store *a,
+                                            const sift3d_descriptor_store *b, double nn_thresh,
+                                            int *match_ab);
+SIFT3D_AMD_API double sift3d_amd_matcher_seconds(const sift3d_amd_matcher *);
+SIFT3D_AMD_API int sift3d_amd_descriptor_store_keep_device(sift3d_descriptor_store *, int on);
 SIFT3D_AMD_API int
 sift3d_amd_descriptor_store_xyz(const sift3d_descriptor_store *, int i, double *xyz /*3*/);
 
@@ -437,6 +452,11 @@ SIFT3D_AMD_API size_t sift3d_hip_describe_wlut_floats(int nlevels);
 SIFT3D_AMD_API int
 sift3d_hip_describe_wlut(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
                          uint32_t n, float *d_hist, float *d_wlut, void *stream);
+/* The same with a second destination: d_hist2 (device memory, may be NULL) receives a copy of every
+ * histogram -- the matcher's input stays in HBM (sift3d_amd_descriptor_store_keep_device). */
+SIFT3D_AMD_API int
+sift3d_hip_describe_wlut2(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
+                          uint32_t n, float *d_hist, float *d_hist2, float *d_wlut, void *stream);
 
 /* Icosahedron face table for the descriptor kernel (init_geometry, sift.c:148-259;
  * per-face constants of cart2bary, sift.c:276-297).  20 records of

@@ -17,6 +17,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _require_built():
+    """These entry points run under rocprofv3, whose preloaded library has already initialised the GPU:
+    building from here (a fork + exec of make) is not allowed on this pool.  Build first."""
+    lib = os.environ.get("SIFT3D_AMD_LIB") or os.path.join(ROOT, "sift3d_amd", "libsift3d_amd.so")
+    if not os.path.exists(lib):
+        sys.exit("%s is missing -- build first: python3 -c \"from sift3d_amd import _native; "
+                 "_native.build()\"" % lib)
+
+
+def run_guarded(*a, **k):
+    _require_built()
+    return run(*a, **k)
+
+
 def run(n=512):
     import torch
     from sift3d_amd import api, hip
@@ -35,6 +49,7 @@ def count():
     L = api.lib()
     L.sift3d_amd_diag_desc_voxels.restype = C.c_ulonglong
     L.sift3d_amd_diag_desc_voxels()
+    _require_built()
     det, kp, desc = run()
     print(json.dumps(dict(window_voxels=int(L.sift3d_amd_diag_desc_voxels()), keypoints=len(kp))))
 
@@ -50,6 +65,8 @@ def parse(d, voxels):
                valu_insts=c.get("SQ_INSTS_VALU"), salu_insts=c.get("SQ_INSTS_SALU"),
                lds_insts=c.get("SQ_INSTS_LDS"), lds_array_cycles=c.get("SQ_LDS_IDX_ACTIVE"),
                lds_bank_conflict_cycles=c.get("SQ_LDS_BANK_CONFLICT"), waves=c.get("SQ_WAVES"),
+               wave_quad_cycles=c.get("SQ_WAVE_CYCLES"), wait_any=c.get("SQ_WAIT_ANY"),
+               wait_inst_any=c.get("SQ_WAIT_INST_ANY"), wait_inst_lds=c.get("SQ_WAIT_INST_LDS"),
                cycles_per_valu=2.5,
                note="wave-instructions per launch (rocprofv3 --pmc); one VALU instruction occupies a "
                     "SIMD for ~2.5 cycles (scratch microbenchmark, plain f32 ops); "
@@ -67,6 +84,9 @@ def parse(d, voxels):
                record_read_b128=24,                         # 3 fields x 4 chunks x 2 passes
                record_write2_b32=6, record_write_b32=2,     # 7 dwords per lane per pass
                face_read_b128=4, octant_read_b32=1, queue_read_b32=1, queue_write_b32=2)
+    out["issue_model_note"] = ("an LDS instruction priced at what the back-to-back microbenchmark measured "
+                               "(lds_cost_mi355x.txt); the counters (SQ_LDS_IDX_ACTIVE, SQ_WAIT_INST_LDS) are "
+                               "what the hardware reports for this kernel -- bench.py prints both")
     cyc = (mix["rmw_read_b32"] * cost["read_b32"] + mix["rmw_write_b32"] * cost["write_b32"] +
            mix["record_read_b128"] * cost["read_b128"] + mix["record_write2_b32"] * cost["write2_b32"] +
            mix["record_write_b32"] * cost["write_b32"] + mix["face_read_b128"] * cost["read_b128"] +
@@ -82,7 +102,7 @@ def parse(d, voxels):
 
 if __name__ == "__main__":
     if "--run" in sys.argv:
-        run()
+        run_guarded()
     elif "--count" in sys.argv:
         count()
     elif "--parse" in sys.argv:

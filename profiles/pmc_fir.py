@@ -14,8 +14,22 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+
+def _require_built():
+    """These entry points run under rocprofv3, whose preloaded library has already initialised the GPU:
+    building from here (a fork + exec of make) is not allowed on this pool.  Build first."""
+    lib = os.environ.get("SIFT3D_AMD_LIB") or os.path.join(ROOT, "sift3d_amd", "libsift3d_amd.so")
+    if not os.path.exists(lib):
+        sys.exit("%s is missing -- build first: python3 -c \"from sift3d_amd import _native; "
+                 "_native.build()\"" % lib)
+
 SIG = [0.5387011637869722, 0.9732939207323564, 1.2262734984654078, 1.5450077936447955,
        1.9465878414647133, 2.4525469969308156]
+
+
+def run_guarded(*a, **k):
+    _require_built()
+    return run(*a, **k)
 
 
 def run(n=512, reps=3):
@@ -67,4 +81,4 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--parse":
         print(json.dumps(parse(sys.argv[2], sys.argv[3]), indent=1, sort_keys=True))
     else:
-        run()
+        run_guarded()

@@ -82,6 +82,7 @@ def lib():
         "sift3d_amd_descriptor_store_size": (C.c_int, [vp]),
         "sift3d_amd_descriptor_store_set": (C.c_int, [vp, C.c_int, _f64p, _f32p, C.c_int, C.c_int, C.c_int]),
         "sift3d_amd_nn_match": (C.c_int, [vp, vp, C.c_double, _i32p]),
+        "sift3d_amd_descriptor_store_keep_device": (C.c_int, [vp, C.c_int]),
         "sift3d_amd_descriptor_store_xyz": (C.c_int, [vp, C.c_int, _f64p]),
         "sift3d_amd_ransac_affine": (C.c_int, [_f64p, _f64p, C.c_int, C.c_double, C.c_int, C.c_uint64,
                                               _f64p, np.ctypeslib.ndpointer(np.uint8),
@@ -280,6 +281,14 @@ class DescriptorStore:
     def save(self, path):
         return lib().sift3d_descriptor_store_save(path.encode(), self.h)
 
+    def keep_device(self, on=True):
+        """Keep a copy of the histograms in HBM (written by extract_descriptors) for the matcher."""
+        return lib().sift3d_amd_descriptor_store_keep_device(self.h, int(bool(on)))
+
+    def xyz(self):
+        """Keypoint coordinates in octave-0 voxels, one row per descriptor."""
+        return self.to_mat_rm()[:, :3].astype(np.float64)
+
     def set(self, xyz_sd, hist, dims=(0, 0, 0)):
         """Fill the store from host arrays (tests of the writers without a device)."""
         xyz_sd = np.ascontiguousarray(xyz_sd, np.float64).reshape(-1, 4)
@@ -391,6 +400,41 @@ def gauss_filter(sigma):
 
 
 # ---- registration (BASELINE config 5; parity unpinned: removed from the reference fork) --------
+class Matcher:
+    """sift3d_amd_matcher: descriptor matching with reusable device scratch."""
+
+    def __init__(self):
+        L = lib()
+        L.sift3d_amd_make_matcher.restype = C.c_void_p
+        L.sift3d_amd_free_matcher.argtypes = [C.c_void_p]
+        L.sift3d_amd_free_matcher.restype = None
+        L.sift3d_amd_matcher_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                               np.ctypeslib.ndpointer(np.int32)]
+        L.sift3d_amd_matcher_seconds.argtypes = [C.c_void_p]
+        L.sift3d_amd_matcher_seconds.restype = C.c_double
+        self.h = L.sift3d_amd_make_matcher()
+        if not self.h:
+            raise RuntimeError("sift3d_amd_make_matcher failed (no HIP device?)")
+
+    def match(self, desc_a, desc_b, nn_thresh=0.8):
+        """match[i] = index in desc_b of the descriptor matched to descriptor i of desc_a, or -1."""
+        out = np.full(max(len(desc_a), 1), -1, np.int32)
+        if lib().sift3d_amd_matcher_match(self.h, desc_a.h, desc_b.h, float(nn_thresh), out) != 0:
+            raise RuntimeError("sift3d_amd_matcher_match failed")
+        return out[:len(desc_a)]
+
+    def seconds(self):
+        """Device seconds of the two nearest-neighbour searches of the last match."""
+        return float(lib().sift3d_amd_matcher_seconds(self.h))
+
+    def free(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib().sift3d_amd_free_matcher(self.h)
+            self.h = None
+
+    __del__ = free
+
+
 def nn_match(desc_a, desc_b, nn_thresh=0.8):
     """match[i] = index in desc_b of the descriptor matched to descriptor i of desc_a, or -1."""
     out = np.full(max(len(desc_a), 1), -1, np.int32)

@@ -169,7 +169,8 @@ constexpr int DWAVES = 4;   // keypoints (waves) per workgroup; they share the r
 
 __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level *__restrict__ levels,
                                                  const sift3d_hip_kp *__restrict__ kps, uint32_t n,
-                                                 float *__restrict__ out, const float *__restrict__ wlut DESC_ABLATE_ARG)
+                                                 float *__restrict__ out, float *__restrict__ out2,
+                                                 const float *__restrict__ wlut DESC_ABLATE_ARG)
 {
     // per wave: 2 * 3200 + 2016 + 1024 B; per workgroup 39.4 KB -> four workgroups = 16 waves per CU
     __shared__ float hist_[DWAVES][2 * HIST_LDS];   // one private histogram per half-wave
@@ -673,8 +674,13 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         }
         wave_sync();
     }
-    for (int i = lane; i < 768; i += 64)
-        out[(size_t)orow * 768 + i] = hist[c_bin_off[i % 12] + i / 12];
+    // (out: the store's page-locked host array; out2: an optional copy that stays in HBM for the matcher)
+    for (int i = lane; i < 768; i += 64) {
+        const float v = hist[c_bin_off[i % 12] + i / 12];
+        out[(size_t)orow * 768 + i] = v;
+        if (out2)
+            out2[(size_t)orow * 768 + i] = v;
+    }
 }
 
 extern "C" {
@@ -820,17 +826,17 @@ size_t sift3d_hip_describe_wlut_floats(int nlevels)
 }
 
 static int describe_launch(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d_kp, uint32_t n,
-                           float *d_hist, const float *d_wlut, void *stream)
+                           float *d_hist, float *d_hist2, const float *d_wlut, void *stream)
 {
 #ifdef SIFT3D_AMD_DIAG
     // diagnostic build only (wrong results): 1 skips the commit, 2 the whole batch -- used by
     // profiles/ scripts to attribute the kernel's time to scan / per-voxel terms / commit
     static int ablate = getenv("SIFT3D_AMD_DESC_ABLATE") ? atoi(getenv("SIFT3D_AMD_DESC_ABLATE")) : 0;
     hipLaunchKernelGGL(k_describe, dim3((n + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
-                       (hipStream_t)stream, d_levels, d_kp, n, d_hist, d_wlut, ablate);
+                       (hipStream_t)stream, d_levels, d_kp, n, d_hist, d_hist2, d_wlut, ablate);
 #else
     hipLaunchKernelGGL(k_describe, dim3((n + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
-                       (hipStream_t)stream, d_levels, d_kp, n, d_hist, d_wlut);
+                       (hipStream_t)stream, d_levels, d_kp, n, d_hist, d_hist2, d_wlut);
 #endif
     LAUNCH_CHECK();
     return SIFT3D_SUCCESS;
@@ -841,19 +847,25 @@ int sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d
 {
     if (!n)
         return SIFT3D_SUCCESS;
-    return describe_launch(d_levels, d_kp, n, d_hist, nullptr, stream);
+    return describe_launch(d_levels, d_kp, n, d_hist, nullptr, nullptr, stream);
+}
+
+int sift3d_hip_describe_wlut2(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
+                              uint32_t n, float *d_hist, float *d_hist2, float *d_wlut, void *stream)
+{
+    if (!n)
+        return SIFT3D_SUCCESS;
+    if (!d_wlut || nlevels < 1)
+        return describe_launch(d_levels, d_kp, n, d_hist, d_hist2, nullptr, stream);
+    hipLaunchKernelGGL(k_desc_wlut, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, d_levels, nlevels,
+                       d_wlut);
+    return describe_launch(d_levels, d_kp, n, d_hist, d_hist2, d_wlut, stream);
 }
 
 int sift3d_hip_describe_wlut(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
                              uint32_t n, float *d_hist, float *d_wlut, void *stream)
 {
-    if (!n)
-        return SIFT3D_SUCCESS;
-    if (!d_wlut || nlevels < 1)
-        return describe_launch(d_levels, d_kp, n, d_hist, nullptr, stream);
-    hipLaunchKernelGGL(k_desc_wlut, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, d_levels, nlevels,
-                       d_wlut);
-    return describe_launch(d_levels, d_kp, n, d_hist, d_wlut, stream);
+    return sift3d_hip_describe_wlut2(d_levels, nlevels, d_kp, n, d_hist, nullptr, d_wlut, stream);
 }
 
 } // extern "C"

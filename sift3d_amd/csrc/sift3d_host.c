@@ -83,6 +83,10 @@ struct _sift3d_descriptor_store {
     double *xyzsd;     /* [num][4]: xd, yd, zd (octave-0 voxels), sd */
     size_t num, cap;
     int pinned;
+    /* optional copy of the histograms in device memory (sift3d_amd_descriptor_store_keep_device) */
+    int keep_device;
+    float *d_hist;
+    size_t d_cap, d_num;   /* d_num == num && d_num > 0: the copy is current */
     int nx, ny, nz;
 };
 
@@ -552,6 +556,9 @@ sift3d_descriptor_store *sift3d_make_descriptor_store()
 
 static void desc_store_release(sift3d_descriptor_store *d)
 {
+    sift3d_hip_free(d->d_hist);
+    d->d_hist = NULL;
+    d->d_cap = d->d_num = 0;
     if (d->pinned)
         sift3d_hip_host_free(d->hist);
     else
@@ -1756,6 +1763,15 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
         desc->cap = cap;
     }
     desc->num = (size_t)num;
+    desc->d_num = 0;
+    if (desc->keep_device && (size_t)num > desc->d_cap) {
+        sift3d_hip_free(desc->d_hist);
+        desc->d_cap = 0;
+        desc->d_hist = (float *)sift3d_hip_malloc(sizeof(float) * DESC_NUMEL * desc->cap);
+        if (!desc->d_hist)
+            return SIFT3D_FAILURE;
+        desc->d_cap = desc->cap;
+    }
     sift3d_hip_event_record(d->ev[6], d->stream);
     if (sift3d_hip_memcpy_h2d(d->d_kp, d->h_kp, sizeof(sift3d_hip_kp) * (size_t)num, d->stream))
         return SIFT3D_FAILURE;
@@ -1766,8 +1782,10 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
      * pays the kernel's long tail.) */
     {
         float *dev_view = (float *)sift3d_hip_host_device_ptr(desc->hist);
-        if (!dev_view || sift3d_hip_describe_wlut(d->d_levels, d->num_octaves * d->ngl, d->d_kp,
-                                                  (uint32_t)num, dev_view, d->d_wlut, d->stream))
+        if (!dev_view || sift3d_hip_describe_wlut2(d->d_levels, d->num_octaves * d->ngl, d->d_kp,
+                                                   (uint32_t)num, dev_view,
+                                                   desc->keep_device ? desc->d_hist : NULL, d->d_wlut,
+                                                   d->stream))
             return SIFT3D_FAILURE;
     }
     sift3d_hip_event_record(d->ev[7], d->stream);
@@ -1781,6 +1799,8 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
     }
     if (sift3d_hip_stream_sync(d->stream))
         return SIFT3D_FAILURE;
+    if (desc->keep_device)
+        desc->d_num = (size_t)num;
     d->t[5] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[6], d->ev[7]);
     d->t[8] = now_s() - t_start;
     return SIFT3D_SUCCESS;

@@ -81,8 +81,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // k = lane >> 5) read 32 consecutive floats.  Double-buffered: the global loads of chunk
     // c + 1 are in flight during the MFMAs of chunk c and go to the other buffer afterwards --
     // one barrier per chunk.
-    __shared__ float As[2][KC][MT + 4];
-    __shared__ float Bs[2][KC][NT + 4];
+    // row stride 130: the transposing stores of a wave (lanes 2 r and 2 r + 1 write row r of k rows
+    // sk = 0 and 8) land 8 * 130 = 1040 floats apart = 16 banks apart -- with stride 132 the two lanes of
+    // a pair shared a bank (2-way conflict on every staging store); the operand reads stay 32
+    // consecutive floats
+    __shared__ float As[2][KC][MT + 2];
+    __shared__ float Bs[2][KC][NT + 2];
     __shared__ float red_d1[MT][2], red_d2[MT][2];
     __shared__ int red_j[MT][2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;

@@ -133,3 +133,44 @@ def test_config5_two_volumes_match_and_register(n):
     want = np.array([[0, 1.0, 0, -sy], [-1.0, 0, 0, n - 1], [0, 0, 1.0, -sz]])
     assert inl.mean() > 0.8
     assert np.abs(T[:, :3] - want[:, :3]).max() < 0.01 and np.abs(T[:, 3] - want[:, 3]).max() < 0.75
+
+
+@pytest.mark.gpu
+def test_matcher_device_resident_stores_equal_uploaded():
+    """sift3d_amd_matcher on stores that keep their histograms in HBM (written by the describe kernel
+    beside the host array) == the same match on stores uploaded per call; the device copy is dropped
+    when a store is refilled from the host."""
+    import torch
+    from sift3d_amd import api, hip
+    n = 128
+    vol = torch.empty((n + 24, n + 16, n), device="cuda")
+    hip.synth_lattice(vol, 0, 21)
+    v1 = vol[0:n, 0:n, :].contiguous()
+    v2 = vol[9:9 + n, 5:5 + n, :].transpose(1, 2).flip(1).contiguous()
+    torch.cuda.synchronize()
+    out = {}
+    for keep in (False, True):
+        stores = []
+        for v in (v1, v2):
+            det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+            if keep:
+                assert desc.keep_device(True) == 0
+            assert det.detect_keypoints_device(v.data_ptr(), n, n, n, kp) == 0
+            assert det.extract_descriptors(kp, desc) == 0
+            stores.append(desc)
+        m = api.Matcher()
+        a = m.match(stores[0], stores[1], 0.8)
+        b = m.match(stores[0], stores[1], 0.8)             # scratch reused
+        np.testing.assert_array_equal(a, b)
+        assert m.seconds() > 0
+        out[keep] = (a, stores[0].to_mat_rm(), stores[1].to_mat_rm())
+        if keep:
+            # refilled from host arrays: the (now stale) device copy must not be used
+            mat = stores[1].to_mat_rm()
+            assert stores[1].set(np.zeros((len(mat), 4)), mat[::-1, 3:].copy()) == 0
+            c = m.match(stores[0], stores[1], 0.8)
+            ok = a >= 0
+            np.testing.assert_array_equal(c[ok], len(mat) - 1 - a[ok])
+    np.testing.assert_array_equal(out[False][0], out[True][0])
+    np.testing.assert_array_equal(out[False][1], out[True][1])
+    assert (out[True][0] >= 0).sum() > 20
