@@ -132,8 +132,8 @@ struct _sift3d_detector {
     sift3d_hip_level *h_levels, *d_levels;
     sift3d_hip_cand *d_cand, *h_cand;
     uint32_t cand_cap;
-    float *d_R, *h_R;
-    int32_t *d_keep, *h_keep;
+    float *h_R;            /* page-locked, device-visible: the orientation kernels write here */
+    int32_t *h_keep;
     void *d_work;
     size_t work_bytes;
     void *d_work2;         /* extrema work areas of octaves >= 1 (kept between the two phases) */
@@ -1134,8 +1134,6 @@ void sift3d_free_detector(sift3d_detector *d)
     free_filters(d);
     sift3d_hip_free(d->d_in);
     sift3d_hip_free(d->d_cand);
-    sift3d_hip_free(d->d_R);
-    sift3d_hip_free(d->d_keep);
     sift3d_hip_free(d->d_kp);
     sift3d_hip_host_free(d->h_cand);
     sift3d_hip_host_free(d->h_R);
@@ -1213,19 +1211,15 @@ static int ensure_cand_capacity(sift3d_detector *d, uint32_t cap)
     if (cap <= d->cand_cap)
         return SIFT3D_SUCCESS;
     sift3d_hip_free(d->d_cand);
-    sift3d_hip_free(d->d_R);
-    sift3d_hip_free(d->d_keep);
     sift3d_hip_host_free(d->h_cand);
     sift3d_hip_host_free(d->h_R);
     sift3d_hip_host_free(d->h_keep);
     d->cand_cap = 0;
     d->d_cand = (sift3d_hip_cand *)sift3d_hip_malloc(sizeof(sift3d_hip_cand) * (size_t)cap);
-    d->d_R = (float *)sift3d_hip_malloc(sizeof(float) * 9 * (size_t)cap);
-    d->d_keep = (int32_t *)sift3d_hip_malloc(sizeof(int32_t) * (size_t)cap);
     d->h_cand = (sift3d_hip_cand *)sift3d_hip_host_alloc(sizeof(sift3d_hip_cand) * (size_t)cap);
     d->h_R = (float *)sift3d_hip_host_alloc(sizeof(float) * 9 * (size_t)cap);
     d->h_keep = (int32_t *)sift3d_hip_host_alloc(sizeof(int32_t) * (size_t)cap);
-    if (!d->d_cand || !d->d_R || !d->d_keep || !d->h_cand || !d->h_R || !d->h_keep)
+    if (!d->d_cand || !d->h_cand || !d->h_R || !d->h_keep)
         return SIFT3D_FAILURE;
     d->cand_cap = cap;
     return SIFT3D_SUCCESS;
@@ -1574,16 +1568,21 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                 return SIFT3D_FAILURE;
             d->otab_bytes = need;
         }
-        if (sift3d_hip_orient_tab(d->d_levels, d->num_octaves * d->ngl, d->d_cand, count, d->corner_thresh,
-                                  d->d_R, d->d_keep, d->d_otab, d->cand_cap, d->stream) ||
+        /* The candidate records are final (the host has just read their count): their copy runs on the
+         * side stream beside the orientation kernels.  R and the keep flags are written by the kernels
+         * straight into the page-locked host arrays (mapped into the device's address space; only kept
+         * candidates' matrices are written): no device staging, no copy after the kernels. */
+        float *r_view = (float *)sift3d_hip_host_device_ptr(d->h_R);
+        int32_t *k_view = (int32_t *)sift3d_hip_host_device_ptr(d->h_keep);
+        if (!r_view || !k_view ||
             sift3d_hip_memcpy_d2h(d->h_cand, d->d_cand, sizeof(sift3d_hip_cand) * (size_t)count,
-                                  d->stream) ||
-            sift3d_hip_memcpy_d2h(d->h_R, d->d_R, sizeof(float) * 9 * (size_t)count, d->stream) ||
-            sift3d_hip_memcpy_d2h(d->h_keep, d->d_keep, sizeof(int32_t) * (size_t)count, d->stream))
+                                  d->oct_stream) ||
+            sift3d_hip_orient_tab(d->d_levels, d->num_octaves * d->ngl, d->d_cand, count, d->corner_thresh,
+                                  r_view, k_view, d->d_otab, d->cand_cap, d->stream))
             return SIFT3D_FAILURE;
     }
     sift3d_hip_event_record(d->ev[5], d->stream);
-    if (sift3d_hip_stream_sync(d->stream))
+    if (sift3d_hip_stream_sync(d->stream) || (count && sift3d_hip_stream_sync(d->oct_stream)))
         return SIFT3D_FAILURE;
 
     /* keypoint store: dimensions of the first octave (sift.c:756-759), then the in-place

@@ -2360,9 +2360,12 @@ __global__ __launch_bounds__(64) void k_orient_decide(const sift3d_hip_cand *__r
                 kept = 2;
         }
     }
+    // (Rout / keep may be page-locked host memory: only what the host will read is written)
+    if (kept == 1) {
 #pragma unroll
-    for (int k = 0; k < 9; k++)
-        Rout[(size_t)ci * 9 + k] = kept == 1 ? R[k] : 0.0f;
+        for (int k = 0; k < 9; k++)
+            Rout[(size_t)ci * 9 + k] = R[k];
+    }
     keep[ci] = kept;
     // the list of the undecided (its order varies from run to run; every entry is computed on its
     // own, so the results do not)
