@@ -2192,24 +2192,24 @@ __global__ __launch_bounds__(64 * ORI_CPW) void k_orient_sums(const sift3d_hip_l
     };
     const f4v zero4 = { 0.f, 0.f, 0.f, 0.f };
     if (interior) {
-        // Two chunks of 64 quads per iteration, their table entries requested one iteration ahead:
-        // an iteration then exposes ONE memory round trip (the twelve sample loads of its two chunks,
-        // all in flight together) instead of four (entries, then samples, per chunk) -- this loop is
-        // bound by load latency, not by bytes or arithmetic (profiles/: ablations of either change
-        // nothing).  Idle lanes and chunks beyond the end repeat the last quad with weight 0.
+        // One chunk of 64 quads per iteration, its table entries requested one iteration ahead (the
+        // sample addresses come out of the entries: without the lookahead every chunk would expose two
+        // dependent memory round trips).  Measured 1.89 / 1.96 / 1.98 / 2.05 ms for 1 / 2 / 3 / 4 chunks per
+        // iteration: more chunks in flight per wave cost registers, i.e. waves (5 per SIMD at 92 VGPRs;
+        // forcing 6-8 waves per SIMD spills: 2.03 / 2.28 / 3.2 ms; a lean launch for the unclipped windows
+        // alone fits 6 waves and gains nothing).  Idle lanes repeat the last quad with weight 0.
         const uint32_t last = count - 1;
         auto slot = [&](uint32_t t0) -> uint32_t { return min(t0 + (uint32_t)lane, last); };
-        u2v mA = meta[slot(0)], mB = meta[slot(64)];
-        f4v wA = wts[slot(0)], wB = wts[slot(64)];
-        for (uint32_t t0 = 0; t0 < count; t0 += 128) {
-            const u2v nA = meta[slot(t0 + 128)], nB = meta[slot(t0 + 192)];     // next iteration's entries
-            const f4v vA = wts[slot(t0 + 128)], vB = wts[slot(t0 + 192)];
-            Quad qA, qB;
-            load_quad(centre + (int)mA.y, qA);
-            load_quad(centre + (int)mB.y, qB);
-            sum_quad(qA, t0 + (uint32_t)lane < count ? wA : zero4);
-            sum_quad(qB, t0 + 64 + (uint32_t)lane < count ? wB : zero4);
-            mA = nA; mB = nB; wA = vA; wB = vB;
+        u2v mc = meta[slot(0)];
+        f4v wc = wts[slot(0)];
+        for (uint32_t t0 = 0; t0 < count; t0 += 64) {
+            const u2v mn = meta[slot(t0 + 64)];            // next iteration's entries
+            const f4v wn = wts[slot(t0 + 64)];
+            Quad q;
+            load_quad(centre + (int)mc.y, q);
+            sum_quad(q, t0 + (uint32_t)lane < count ? wc : zero4);
+            mc = mn;
+            wc = wn;
         }
         nvox = (double)head[7];
     } else {
