@@ -193,12 +193,16 @@ SIFT3D_AMD_API void sift3d_amd_rccl_transport_free(sift3d_amd_transport *t);
 
 /* sift3d_detect_keypoints + sift3d_extract_descriptors (sift.c:1217-1249, 1615-1635) on ONE
  * nx*ny*nz volume cut into `world` Z-slabs; results equal the single-GPU ones bit for bit.
- * `params` supplies thresholds and scales (NULL: defaults); only the default configuration
- * (3 keypoint levels per octave, 8-neighbour extrema, rows of whole quads in every octave) is
- * supported -- create returns NULL otherwise.  This rank's raw planes [z0, z1) go to the device
+ * `params` supplies thresholds, scales, the number of keypoint levels per octave and the extrema
+ * neighbourhood (NULL: defaults); every configuration the drop-in API accepts is supported.  This rank's raw planes [z0, z1) go to the device
  * buffer sift3d_amd_sharded_input() (x fastest, (z1 - z0) * ny * nx floats).  detect fills `kp`
  * with the GLOBAL keypoint list on every rank; describe computes the descriptors of the
- * keypoints this rank owns (their positions in `kp` go to own_idx, capacity kp's size). */
+ * keypoints this rank owns (their positions in `kp` go to own_idx, capacity kp's size).
+ * Failures: detect / describe are collective.  A failure that every rank sees (bad arguments, a
+ * transport error) returns SIFT3D_FAILURE everywhere; a rank-LOCAL failure between two collectives (out of
+ * memory, a halo that does not fit the slab) returns SIFT3D_FAILURE on that rank only while the others
+ * wait in the next collective -- the caller must then abort the communicator (as after any failed
+ * collective), there is no in-band status exchange. */
 typedef struct sift3d_amd_sharded sift3d_amd_sharded;
 SIFT3D_AMD_API sift3d_amd_sharded *
 sift3d_amd_sharded_create(int nx, int ny, int nz, const sift3d_amd_transport *t,
