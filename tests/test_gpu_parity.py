@@ -474,7 +474,7 @@ def test_read_image_then_detect(gpu, oracle_mod, tmp_path):
     assert util.rel_err(desc.to_mat_rm(), o.desc_mat()) <= RTOL
 
 
-@pytest.mark.parametrize("case", ["lattice160", "survey96", "aniso", "corner0", "params"])
+@pytest.mark.parametrize("case", ["lattice160", "survey96", "aniso", "corner0", "params", "wide"])
 def test_orientation_parallel_sums_equal_serial_sums(gpu, oracle_mod, case):
     """sift3d_hip_orient_mode: the default path (parallel double sums, decisions by margin, serial
     re-run of the undecided candidates) must give the keypoint list AND the R bits of the path
@@ -489,6 +489,10 @@ def test_orientation_parallel_sums_equal_serial_sums(gpu, oracle_mod, case):
         vol, units = oracle_mod.synth_survey((72, 60, 81)), (1.0, 1.5, 0.7)
     elif case == "corner0":
         vol, kw = oracle_mod.synth_lattice(80, seed=5), dict(corner_thresh=0.0, peak_thresh=0.02)
+    elif case == "wide":
+        # sigma0 = 5: orientation spheres of 36-45 voxels radius -- beyond the window tables' capacity, so
+        # every candidate of those levels goes through the serial re-run
+        vol, kw = oracle_mod.synth_survey(72), dict(sigma0=5.0, peak_thresh=0.02, corner_thresh=0.2)
     else:
         vol, kw = oracle_mod.synth_survey(64), dict(num_kp_levels=2, sigma0=2.0, sigma_n=1.0,
                                                     peak_thresh=0.05, corner_thresh=0.3)
