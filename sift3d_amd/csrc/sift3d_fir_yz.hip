@@ -217,9 +217,14 @@ static void launch_fir_yz(const FirParams &P, const FirTaps &T, const EdgeTab &E
                           int ty, hipStream_t st)
 {
     const int nseg = (P.z_hi - P.z_lo + P.ts - 1) / P.ts;
-    // 128(x) x 32(y) tiles where the rows fill them (512-byte row segments; measured 2 % faster
-    // over the octave-0 pyramid than 64 x 32), 64 x 32 otherwise
-    if ((P.nx & 127) == 0) {
+    // 64(x) x 64(y) tiles on tall volumes: half the halo rows of a 32-row tile per output row (measured
+    // at 512^3: 1-2 % faster at 5-7 taps, 3-4.5 % at 9-17 taps than 128 x 32); else 128(x) x 32(y) where
+    // the rows fill them (512-byte row segments; 2 % faster over the octave-0 pyramid than 64 x 32),
+    // 64 x 32 otherwise
+    if ((P.nx & 63) == 0 && P.ny >= 128) {
+        dim3 grid((P.nx / 4 + 15) / 16, (P.ny + 63) / 64, nseg);
+        hipLaunchKernelGGL((k_fir_yz_u1<HW, 64, 16>), grid, dim3(1024), 0, st, P, T, Ey, Ez);
+    } else if ((P.nx & 127) == 0) {
         dim3 grid((P.nx / 4 + 31) / 32, (P.ny + 31) / 32, nseg);
         hipLaunchKernelGGL((k_fir_yz_u1<HW, 32, 32>), grid, dim3(1024), 0, st, P, T, Ey, Ez);
     } else {

@@ -165,7 +165,8 @@ def test_fir_slab_z(gpu, oracle_mod):
             np.testing.assert_array_equal(got[z0 - lo:z1 - lo], whole[z0:z1])
 
 
-@pytest.mark.parametrize("shape", [(40, 48, 64), (70, 33, 128), (24, 100, 20), (36, 80, 256)])
+@pytest.mark.parametrize("shape", [(40, 48, 64), (70, 33, 128), (24, 100, 20), (36, 80, 256), (22, 150, 128),
+                                   (30, 128, 64)])
 def test_fir_fused_yz_vs_oracle(gpu, oracle_mod, shape):
     """Fused y+z kernel == FIR_z(FIR_y(.)) of the oracle, whole volume and as Z-slabs (partial
     tiles in x and y, both global z faces, interior slab faces)."""
