@@ -104,7 +104,9 @@ def kernel_microbench(torch, hip, n, reps=10):
         x_ms = [ev[3 * r].elapsed_time(ev[3 * r + 1]) for r in range(reps)]
         yz_ms = [ev[3 * r + 1].elapsed_time(ev[3 * r + 2]) for r in range(reps)]
         row("k_fir_x_u1<%d>" % hw, hw, 0, 8.0, x_ms, True)
-        row("k_fir_yz_u1<%d, 32, %d>" % (hw, 32 if n % 128 == 0 else 16), hw, 12, 16.0, yz_ms, True)   # two 1-D passes = 16 B/voxel
+        # (the launcher's tile choice, sift3d_fir_yz.hip: 64 x 64 on tall volumes, else 128 x 32 / 64 x 32)
+        tile = "64, 16" if (n % 64 == 0 and n >= 128) else ("32, 32" if n % 128 == 0 else "32, 16")
+        row("k_fir_yz_u1<%d, %s>" % (hw, tile), hw, 12, 16.0, yz_ms, True)   # two 1-D passes = 16 B/voxel
 
         def timed(fn):
             fn()

@@ -154,6 +154,8 @@ SIFT3D_AMD_API double sift3d_amd_matcher_seconds(const sift3d_amd_matcher *);
 SIFT3D_AMD_API int sift3d_amd_descriptor_store_keep_device(sift3d_descriptor_store *, int on);
 SIFT3D_AMD_API int
 sift3d_amd_descriptor_store_xyz(const sift3d_descriptor_store *, int i, double *xyz /*3*/);
+SIFT3D_AMD_API int
+sift3d_amd_descriptor_store_xyz_all(const sift3d_descriptor_store *, double *xyz /*3 per descriptor*/);
 
 /* RANSAC fit of the affine map dst = A [src; 1] (tform: 3 x 4 doubles, row-major) to n point
  * pairs (n x 3 doubles each): num_iter minimal samples of 4 pairs, inliers = residual <=

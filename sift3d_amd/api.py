@@ -83,6 +83,7 @@ def lib():
         "sift3d_amd_descriptor_store_set": (C.c_int, [vp, C.c_int, _f64p, _f32p, C.c_int, C.c_int, C.c_int]),
         "sift3d_amd_nn_match": (C.c_int, [vp, vp, C.c_double, _i32p]),
         "sift3d_amd_descriptor_store_keep_device": (C.c_int, [vp, C.c_int]),
+        "sift3d_amd_descriptor_store_xyz_all": (C.c_int, [vp, _f64p]),
         "sift3d_amd_descriptor_store_xyz": (C.c_int, [vp, C.c_int, _f64p]),
         "sift3d_amd_ransac_affine": (C.c_int, [_f64p, _f64p, C.c_int, C.c_double, C.c_int, C.c_uint64,
                                               _f64p, np.ctypeslib.ndpointer(np.uint8),
@@ -287,7 +288,10 @@ class DescriptorStore:
 
     def xyz(self):
         """Keypoint coordinates in octave-0 voxels, one row per descriptor."""
-        return self.to_mat_rm()[:, :3].astype(np.float64)
+        out = np.zeros((max(len(self), 1), 3), np.float64)
+        if lib().sift3d_amd_descriptor_store_xyz_all(self.h, out.reshape(-1)) != 0:
+            raise RuntimeError("sift3d_amd_descriptor_store_xyz_all failed")
+        return out[:len(self)]
 
     def set(self, xyz_sd, hist, dims=(0, 0, 0)):
         """Fill the store from host arrays (tests of the writers without a device)."""

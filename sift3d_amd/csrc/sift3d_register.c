@@ -193,6 +193,17 @@ int sift3d_amd_descriptor_store_xyz(const sift3d_descriptor_store *d, int i, dou
     return SIFT3D_SUCCESS;
 }
 
+/* all coordinates at once: xyz[3 i .. 3 i + 2] = {x, y, z} of descriptor i */
+int sift3d_amd_descriptor_store_xyz_all(const sift3d_descriptor_store *d, double *xyz)
+{
+    size_t i;
+    if (!d || (d->num && !xyz))
+        return SIFT3D_FAILURE;
+    for (i = 0; i < d->num; i++)
+        memcpy(xyz + 3 * i, d->xyzsd + 4 * i, sizeof(double) * 3);
+    return SIFT3D_SUCCESS;
+}
+
 /* solve the 4x4 system M X = R^T for the 3 columns (Gaussian elimination, partial pivoting) */
 static int reg_solve4(double M[4][4], double R[3][4], double A[3][4])
 {
