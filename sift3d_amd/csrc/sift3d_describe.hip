@@ -352,6 +352,25 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     // barriers keep the slices where they are put.  Records of four rounds are read with three
     // 16-byte loads, one chunk ahead.
 #define SB() __builtin_amdgcn_sched_barrier(0)
+// DESC_OPT (bit mask, A/B builds only; the shipped value is the default below):
+//   1 the commit adds mag*w_cell*bary to the bin with ONE fused multiply-add (the product is not rounded
+//     separately: one VALU instruction less per round, the term at least as accurate)
+//   2 the face GUESS with fused multiply-adds; the gradient magnitude by v_sqrt_f32 (1 ulp: a RELATIVE
+//     error of 6e-8 on the term).  The barycentrics keep cart2bary's separately rounded operations and
+//     the IEEE division: b0 = 1 - b1 - b2 carries the rounding noise of b1 and b2 (6e-8 ABSOLUTE), so a
+//     bin fed by a few voxels with a small b0 only agrees with the reference to 1e-5 relative if that
+//     noise is reproduced bit for bit (the FMA / v_rcp_f32 variant was 5 % faster and is not used)
+//   4 window scan: a cheap test with margins decides, the exact one only where a lane is in doubt
+#ifndef DESC_OPT
+#define DESC_OPT 7
+#endif
+#if DESC_OPT & 1
+#define COMMIT_VAL(m, b) 0.0f
+#define COMMIT_ADD(old, val, m, b) __builtin_fmaf(m, b, old)
+#else
+#define COMMIT_VAL(m, b) ((m) * (b))
+#define COMMIT_ADD(old, val, m, b) ((old) + (val))
+#endif
 // a value is computed in the slice that names it here (not sunk to its first use in a later one)
 #define KEEP(v) asm volatile("" ::"v"(v))
 #define COMMIT_BEGIN()                                                                        \
@@ -370,7 +389,8 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         const int mb_[4] = { cb4.x, cb4.y, cb4.z, cb4.w };                                    \
         const float mv_[4] = { cw4.x, cw4.y, cw4.z, cw4.w }, bv_[4] = { cx4.x, cx4.y, cx4.z, cx4.w }; \
         float *bin_ = reinterpret_cast<float *>(reinterpret_cast<char *>(hist) + (mb_[(u) & 3] + coff4)); \
-        const float val_ = mv_[(u) & 3] * bv_[(u) & 3];                   /* sift.c:1371-1373 */ \
+        const float val_ = COMMIT_VAL(mv_[(u) & 3], bv_[(u) & 3]);        /* sift.c:1371-1373 */ \
+        (void)val_;                                                                           \
         float old_ = 0.0f;                                                                    \
         if (!DESC_ABLATE(1))                                                                  \
             old_ = *bin_;                                                                     \
@@ -378,7 +398,7 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         { __VA_ARGS__ }                                                                       \
         SB();                                                                                 \
         if (!DESC_ABLATE(1))                                                                  \
-            *bin_ = old_ + val_;                                                              \
+            *bin_ = COMMIT_ADD(old_, val_, mv_[(u) & 3], bv_[(u) & 3]);                       \
         if (((u) & 3) == 3) {                                                                 \
             cb4 = nb4;                                                                        \
             cw4 = nw4;                                                                        \
@@ -438,9 +458,18 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
             // (face_eval), and accept it when it passes with all barycentrics > 2e-5 (then every
             // other face fails by a wide margin and the first match is unique); anything else --
             // ~1e-4 of the voxels -- takes the reference's scan over all 20 faces.
+#if DESC_OPT & 2
+            // (the guess may be computed any way: no decision rests on it)
+            ROUND(7, const float g = 1.6180339887f, g2 = 2.6180339887f;
+                     const float ax_ = fabsf(rx), ay_ = fabsf(ry), az_ = fabsf(rz);
+                     t1 = __builtin_fmaf(g2, ay_, __builtin_fmaf(-g, az_, ax_));
+                     t2 = __builtin_fmaf(g2, az_, __builtin_fmaf(-g, ax_, ay_));
+                     t3 = __builtin_fmaf(g2, ax_, __builtin_fmaf(-g, ay_, az_));)
+#else
             ROUND(7, const float g = 1.6180339887f, g2 = 2.6180339887f;
                      const float ax_ = fabsf(rx), ay_ = fabsf(ry), az_ = fabsf(rz);
                      t1 = ax_ + g2 * ay_ - g * az_; t2 = ay_ + g2 * az_ - g * ax_; t3 = az_ + g2 * ax_ - g * ay_;)
+#endif
             // (a value read from LDS in one slice is used in a LATER one, so that no slice waits)
             ROUND(8, const int n1 = t1 < 0.0f, n2 = t2 < 0.0f, n3 = t3 < 0.0f;
                      const int cls = n1 + (1 - n1) * (2 * n2 + (1 - n2) * 3 * n3);
@@ -509,7 +538,11 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
             // Voxels without a contribution: magnitude 0 (all eight weights become +-0; the stale
             // values behind them are finite), barycentrics 0 (0 * NaN would be NaN); their bin
             // addresses stay valid ones.
+#if DESC_OPT & 2
+            ROUND(4, mag = __builtin_amdgcn_sqrtf(m2); mag = live && found ? mag : 0.0f;) // sift.c:1331 (1 ulp)
+#else
             ROUND(4, mag = sqrtf(m2); mag = live && found ? mag : 0.0f;)               // sift.c:1331
+#endif
             ROUND(5, fx = vbx - floorf(vbx); fy = vby - floorf(vby); fz = vbz - floorf(vbz);
                      ix = (int)vbx; iy = (int)vby; iz = (int)vbz;)
             ROUND(6, const bool lx = ix >= 3; const bool ly = iy >= 3; const bool lz = iz >= 3;
@@ -561,6 +594,19 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     const float cube_z = half_w * (fabsf(R[6]) + fabsf(R[7]) + fabsf(R[8])) * 1.001f;
     const int zs = max(B.zs, (int)floorf(K.cz - cube_z / L.uz - 1.0f));
     const int ze = min(B.ze, (int)ceilf(K.cz + cube_z / L.uz + 1.0f));
+#if DESC_OPT & 4
+    // The scan's window test in two tiers.  The bin coordinates of voxel (pxs + xx, pys + yy) of a plane
+    // are affine in (xx, yy): vb_i = c_i + a_i * xx + b_i * yy, sq = (dx0 + ux * xx)^2 + (dy0 + uy * yy)^2
+    // + dz^2 -- 14 fused multiply-adds and conversions instead of the reference's 27 separately rounded
+    // operations.  Both evaluations are within ~3e-6 of the real value (|vb| < 6, six to eight roundings
+    // of 2^-24 relative each; sq: relative), so a voxel that passes the cheap test by MARGIN 1e-4 passes
+    // the reference's test, one that fails it by that margin fails the reference's, and the exact
+    // expressions (window()) decide only for chunks in which some lane falls inside the margin (~2 % of
+    // the chunks; NaNs compare false on both sides and land there too).  Every decision is the reference's.
+    const float wa0 = R[0] * L.ux * bin_f, wa1 = R[1] * L.ux * bin_f, wa2 = R[2] * L.ux * bin_f;
+    const float wb0 = R[3] * L.uy * bin_f, wb1 = R[4] * L.uy * bin_f, wb2 = R[5] * L.uy * bin_f;
+    const float rad2_in = rad2 * 0.9999f, rad2_out = rad2 * 1.0001f;
+#endif
     for (int z = zs; z <= ze; z++) {
         const float dzp = ((float)z - K.cz) * L.uz;
         const float rz = sqrtf(fmaxf(rad2 - dzp * dzp, 0.0f)) * 1.001f;
@@ -570,6 +616,25 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         const int pbx = pxe - pxs + 1, pby = pye - pys + 1;
         const int ppl = pbx > 0 && pby > 0 ? pbx * pby : 0;
         const int ox = pxs - B.xs, oy = pys - B.ys;
+#if DESC_OPT & 4
+        const float dx0 = ((float)pxs - K.cx) * L.ux, dy0 = ((float)pys - K.cy) * L.uy, dz2 = dzp * dzp;
+        const float wc0 = (R[0] * dx0 + R[3] * dy0 + R[6] * dzp + half_w) * bin_f;
+        const float wc1 = (R[1] * dx0 + R[4] * dy0 + R[7] * dzp + half_w) * bin_f;
+        const float wc2 = (R[2] * dx0 + R[5] * dy0 + R[8] * dzp + half_w) * bin_f;
+        // acc: passes by margin; the return value: neither passes nor fails by margin
+        auto cheap = [&](int xx_, int yy_, bool &acc) -> bool {
+            const float fx_ = (float)xx_, fy_ = (float)yy_;
+            const float v0 = __builtin_fmaf(wa0, fx_, __builtin_fmaf(wb0, fy_, wc0));
+            const float v1 = __builtin_fmaf(wa1, fx_, __builtin_fmaf(wb1, fy_, wc1));
+            const float v2 = __builtin_fmaf(wa2, fx_, __builtin_fmaf(wb2, fy_, wc2));
+            const float ex = __builtin_fmaf(fx_, L.ux, dx0), ey = __builtin_fmaf(fy_, L.uy, dy0);
+            const float sq_ = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, dz2));
+            const float lo = fminf(fminf(v0, v1), v2), hi = fmaxf(fmaxf(v0, v1), v2);
+            acc = sq_ <= rad2_in && lo >= 1e-4f && hi <= 3.9999f;
+            const bool rej = sq_ > rad2_out || lo < -1e-4f || hi >= 4.0001f;
+            return !acc && !rej;
+        };
+#endif
         // (yy, xx) of this lane's voxel in the rectangle; a chunk of 64 voxels further it is
         // (yy + q64, xx + r64), one more row if xx wraps.  Two chunks are tested per iteration
         // (independent arithmetic: the second hides the latency of the first).
@@ -581,9 +646,21 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
                 xx1 -= pbx;
                 yy1++;
             }
+#if DESC_OPT & 4
+            bool in0, in1;
+            const bool d0 = cheap(xx, yy, in0), d1 = cheap(xx1, yy1, in1);
+            if (__builtin_expect(__ballot(d0 || d1) != 0ull, 0)) {
+                float sq, vbx, vby, vbz;
+                in0 = window(pxs + xx, pys + yy, z, sq, vbx, vby, vbz);
+                in1 = window(pxs + xx1, pys + yy1, z, sq, vbx, vby, vbz);
+            }
+            in0 = in0 && c0 + lane < ppl;
+            in1 = in1 && c0 + 64 + lane < ppl;
+#else
             float sq, vbx, vby, vbz;
             const bool in0 = window(pxs + xx, pys + yy, z, sq, vbx, vby, vbz) && c0 + lane < ppl;
             const bool in1 = window(pxs + xx1, pys + yy1, z, sq, vbx, vby, vbz) && c0 + 64 + lane < ppl;
+#endif
             const int pk0 = (ox + xx) | ((oy + yy) << 10) | ((z - B.zs) << 20);
             const int pk1 = (ox + xx1) | ((oy + yy1) << 10) | ((z - B.zs) << 20);
             xx = xx1 + r64;
