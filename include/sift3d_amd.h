@@ -57,6 +57,16 @@ sift3d_amd_image_set_units(sift3d_image *im, double ux, double uy, double uz);
 SIFT3D_AMD_API int
 sift3d_amd_detector_set_cuboid_extrema(sift3d_detector *det, int on);
 
+/* The dogmax scan (sift.c:821-826) of octave 0 as a pass of its own over the octave's Gaussian levels
+ * (non-zero) or gathered by the extrema sweep from lower bounds (0, the default: see
+ * sift3d_hip_extrema_gauss6_est_phase).  Same candidates either way; an A/B switch for tests and profiles. */
+SIFT3D_AMD_API int
+sift3d_amd_detector_set_dogmax_pass(sift3d_detector *det, int on);
+/* max|DoG| of every DoG level of the last detect call, out[octave * levels + level] (the values
+ * detect_extrema scales peak_thresh with, sift.c:821-829); returns their number, -1 on failure. */
+SIFT3D_AMD_API int
+sift3d_amd_detector_dogmax(const sift3d_detector *det, float *out, int cap);
+
 /* Dimensions (nx, ny, nz, nc) and voxel spacing of an image, e.g. one returned by
  * sift3d_read_image (the reference keeps both private).  Either output may be NULL. */
 SIFT3D_AMD_API int
@@ -394,6 +404,22 @@ sift3d_hip_extrema_gauss6_phase(const float *const *d_g, const float *d_absmax, 
                                 int z_lo, int z_hi, int tag0, double peak_thresh, sift3d_hip_cand *d_out,
                                 uint32_t cap, uint32_t *d_count, void *d_work, size_t work_bytes,
                                 void *stream, int phase);
+/* The stage with ONE pass over the octave's Gaussian levels (the dogmax scan of sift.c:821-826 needs no
+ * pass of its own).  sift3d_hip_dogmax_sub: maxima of the five |DoG| levels over the sub-lattice
+ * z = 1, 6, 11, ..., y = 0, 3, 6, ... (one fifteenth of the bytes), atomically maxed into d_est[0..4] (zeroed by the
+ * caller) -- LOWER bounds of the reference's maxima.  sift3d_hip_extrema_gauss6_est_phase: phases as above
+ * on the whole volume (planes 1 .. nz - 2); the sweep marks every extremum above peak_thresh * d_est[level]
+ * -- a superset of the reference's candidates --, gathers the EXACT maxima into d_exact[0..4] (zeroed by the
+ * caller before phase 1) and the reference's threshold (sift.c:829, 842) is then applied to the marked
+ * voxels: candidates and maxima are those of sift3d_hip_dogmax_stack + sift3d_hip_extrema_gauss6_phase.
+ * Both return 1 when the configuration is not covered. */
+SIFT3D_AMD_API int sift3d_hip_dogmax_sub(const float *const *d_g, int nx, int ny, int nz, float *d_est,
+                                         void *stream);
+SIFT3D_AMD_API int
+sift3d_hip_extrema_gauss6_est_phase(const float *const *d_g, const float *d_est, float *d_exact, int nx,
+                                    int ny, int nz, int tag0, double peak_thresh, sift3d_hip_cand *d_out,
+                                    uint32_t cap, uint32_t *d_count, void *d_work, size_t work_bytes,
+                                    void *stream, int phase);
 
 /* Geometry of one Gaussian level, as the window kernels see it (a table of these
  * lives in device memory, indexed by the `tag`/`level` of a record). */

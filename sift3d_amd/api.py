@@ -73,6 +73,8 @@ def lib():
         "sift3d_amd_num_candidates": (C.c_int, [vp]),
         "sift3d_amd_image_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
         "sift3d_amd_detector_set_cuboid_extrema": (C.c_int, [vp, C.c_int]),
+        "sift3d_amd_detector_set_dogmax_pass": (C.c_int, [vp, C.c_int]),
+        "sift3d_amd_detector_dogmax": (C.c_int, [vp, vp, C.c_int]),
         "sift3d_amd_copy_level": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, _i32p]),
         "sift3d_amd_keypoint_store_size": (C.c_int, [vp]),
         "sift3d_amd_keypoint_store_get": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int),
@@ -346,6 +348,18 @@ class Detector:
     def set_cuboid_extrema(self, on):
         """Run-time form of the reference's compile-time CUBOID_EXTREMA (sift.c:24)."""
         return lib().sift3d_amd_detector_set_cuboid_extrema(self.h, int(bool(on)))
+
+    def set_dogmax_pass(self, on):
+        """A/B switch: octave 0's dogmax scan as a pass of its own (True) or gathered by the extrema sweep."""
+        return lib().sift3d_amd_detector_set_dogmax_pass(self.h, int(bool(on)))
+
+    def dogmax(self):
+        """max|DoG| of every DoG level of the last detect call (float32, octave-major)."""
+        out = np.zeros(1024, np.float32)
+        n = lib().sift3d_amd_detector_dogmax(self.h, out.ctypes.data, out.size)
+        if n < 0:
+            raise RuntimeError("sift3d_amd_detector_dogmax")
+        return out[:n].copy()
 
     def detect_keypoints(self, image, store):
         return lib().sift3d_detect_keypoints(self.h, image.h, store.h)

@@ -26,6 +26,7 @@
 #include <string.h>
 #include <time.h>
 #include <zlib.h>
+#include <omp.h>
 
 #include "../../include/sift3d/imutil.h"
 #include "../../include/sift3d/sift.h"
@@ -128,7 +129,10 @@ struct _sift3d_detector {
     size_t in_cap;
     float **d_g, **d_d;    /* [num_octaves*ngl], [num_octaves*ndl] (DoG: only where stored) */
     unsigned char dog_free[64]; /* per octave: the last detect formed its DoG levels on the fly */
-    float *d_scalars;      /* [0] input max, [1] count (as u32), [8 + o*ndl + s] dogmax */
+    float *d_scalars;      /* [0] input max, [1] count (as u32), [8 + o*ndl + s] dogmax, then
+                            * [8 + (num_octaves + o)*ndl + s] their lower bounds (sift3d_hip_dogmax_sub) */
+    int est0;              /* the large octaves' maxima gathered by their extrema sweeps (default; 0: a pass
+                            * of their own) */
     sift3d_hip_level *h_levels, *d_levels;
     sift3d_hip_cand *d_cand, *h_cand;
     uint32_t cand_cap;
@@ -1023,7 +1027,7 @@ static int resize_detector(sift3d_detector *d)
         if (!d->d_tmp2_a || !d->d_tmp2_b || !d->d_tmp3_a || !d->d_tmp3_b)
             return SIFT3D_FAILURE;
     }
-    d->d_scalars = (float *)sift3d_hip_malloc(sizeof(float) * (8 + (size_t)d->num_octaves * ndl));
+    d->d_scalars = (float *)sift3d_hip_malloc(sizeof(float) * (8 + 2 * (size_t)d->num_octaves * ndl));
     d->d_levels = (sift3d_hip_level *)sift3d_hip_malloc(sizeof(sift3d_hip_level) *
                                                         (size_t)d->num_octaves * ngl);
     d->d_work = sift3d_hip_malloc(work);
@@ -1052,6 +1056,14 @@ int sift3d_amd_detector_set_cuboid_extrema(sift3d_detector *d, int on)
     if (!d)
         return SIFT3D_FAILURE;
     d->cuboid_extrema = on ? 1 : 0;
+    return SIFT3D_SUCCESS;
+}
+
+int sift3d_amd_detector_set_dogmax_pass(sift3d_detector *d, int on)
+{
+    if (!d)
+        return SIFT3D_FAILURE;
+    d->est0 = on ? 0 : 1;
     return SIFT3D_SUCCESS;
 }
 
@@ -1114,6 +1126,7 @@ sift3d_detector *sift3d_make_detector()
     if (!d)
         return NULL;
     d->peak_thresh = peak_thresh_default;
+    d->est0 = 1;
     d->corner_thresh = corner_thresh_default;
     d->sigma_n = sigma_n_default;
     d->sigma0 = sigma0_default;
@@ -1159,6 +1172,19 @@ void sift3d_free_detector(sift3d_detector *d)
 
 const double *sift3d_amd_timings(const sift3d_detector *d) { return d->t; }
 int sift3d_amd_num_candidates(const sift3d_detector *d) { return d->ncand; }
+
+/* max|DoG| of every level of the last detect call (the dogmax scan, sift.c:821-826): out[o * ndl + s],
+ * capacity `cap` floats; returns the number of values or -1 */
+int sift3d_amd_detector_dogmax(const sift3d_detector *d, float *out, int cap)
+{
+    const int n = d ? d->num_octaves * d->ndl : 0;
+    if (!d || !out || !d->have_pyramid || !d->d_scalars || n < 1 || cap < n)
+        return -1;
+    if (sift3d_hip_memcpy_d2h(out, d->d_scalars + 8, sizeof(float) * (size_t)n, d->stream) ||
+        sift3d_hip_stream_sync(d->stream))
+        return -1;
+    return n;
+}
 
 /* ------------------------------------------------------------------------ */
 /* the hot path                                                              */
@@ -1319,6 +1345,23 @@ static void level_units(const sift3d_detector *d, int o, double *lu)
 }
 
 /* device part of sift3d_detect_keypoints (sift.c:1217-1249) */
+/* Host loops over the candidate / keypoint lists (10^5 records at 512^3) run between the last kernel of
+ * one stage and the first of the next, with the device idle: a few threads, statically split so that the
+ * order of the records -- the reference's scan order -- is kept. */
+/* octaves whose dogmax scan is gathered by the extrema sweep: those large enough for the saved bytes to
+ * outweigh four more (short) launches */
+#define EST_OCTAVE(d, o) ((d)->est0 && (size_t)(d)->odims[o][0] * (d)->odims[o][1] * (d)->odims[o][2] >= ((size_t)1 << 21))
+#define HOST_THREADS_MAX 8
+static int host_threads(size_t n)
+{
+    int t = omp_get_num_procs();
+    if (t > HOST_THREADS_MAX)
+        t = HOST_THREADS_MAX;
+    if (n < 4096 || t < 1)
+        t = 1;
+    return t;
+}
+
 static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int ny, int nz,
                             double ux, double uy, double uz, sift3d_keypoint_store *kp)
 {
@@ -1327,7 +1370,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                              !d->num_octaves;
     const double t_start = now_s();
     uint32_t count = 0;
-    int o, s, i, j, attempt, side;
+    int o, s, attempt, side;
 
     /* set_im_SIFT3D, sift.c:629-659 */
     d->have_im = 1;
@@ -1344,7 +1387,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
         return SIFT3D_FAILURE;
 
     sift3d_hip_event_record(d->ev[0], d->stream);
-    if (sift3d_hip_memset(d->d_scalars, 0, sizeof(float) * (8 + (size_t)d->num_octaves * d->ndl),
+    if (sift3d_hip_memset(d->d_scalars, 0, sizeof(float) * (8 + 2 * (size_t)d->num_octaves * d->ndl),
                           d->stream) ||
         sift3d_hip_absmax(d_vol, n0, d->d_scalars, d->stream) ||
         sift3d_hip_scale(d_vol, d->d_im, n0, d->d_scalars, d->stream))
@@ -1445,7 +1488,14 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
         const size_t n = (size_t)d->odims[o][0] * d->odims[o][1] * d->odims[o][2];
         int rc = 1;
         d->dog_free[o] = 0;
-        if (!d->cuboid_extrema && d->ngl == 6 && (d->odims[o][0] & 3) == 0 && d->odims[o][2] >= 3)
+        if (side && EST_OCTAVE(d, o))
+            /* the large octaves (nearly all of the pyramid's bytes): lower bounds of their maxima from a
+             * sub-lattice; the extrema sweep gathers the exact ones (sift3d_hip_extrema_gauss6_est_phase) */
+            rc = sift3d_hip_dogmax_sub((const float *const *)(d->d_g + o * d->ngl), d->odims[o][0],
+                                       d->odims[o][1], d->odims[o][2],
+                                       d->d_scalars + 8 + (d->num_octaves + o) * d->ndl,
+                                       o > 0 ? d->oct_stream : d->stream);
+        else if (!d->cuboid_extrema && d->ngl == 6 && (d->odims[o][0] & 3) == 0 && d->odims[o][2] >= 3)
             rc = sift3d_hip_dogmax_stack((const float *const *)(d->d_g + o * d->ngl), d->ngl, n,
                                          d->d_scalars + 8 + o * d->ndl,
                                          side && o > 0 ? d->oct_stream : d->stream);
@@ -1499,6 +1549,17 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                     const size_t wb = o ? sift3d_hip_extrema_work_bytes(d->odims[o][0], d->odims[o][1],
                                                                         d->odims[o][2], 3)
                                         : d->work_bytes;
+                    if (EST_OCTAVE(d, o)) {
+                        if (sift3d_hip_extrema_gauss6_est_phase(
+                                (const float *const *)(d->d_g + o * d->ngl),
+                                d->d_scalars + 8 + (d->num_octaves + o) * d->ndl,
+                                d->d_scalars + 8 + o * d->ndl, d->odims[o][0], d->odims[o][1],
+                                d->odims[o][2], o * d->ngl + 1, d->peak_thresh, d->d_cand, d->cand_cap,
+                                (uint32_t *)(d->d_scalars + 1), wk, wb,
+                                phase == 1 && o > 0 ? d->oct_stream : d->stream, phase))
+                            return SIFT3D_FAILURE;
+                        continue;
+                    }
                     if (sift3d_hip_extrema_gauss6_phase(
                             (const float *const *)(d->d_g + o * d->ngl), d->d_scalars + 8 + o * d->ndl,
                             d->odims[o][0], d->odims[o][1], d->odims[o][2], 1, d->odims[o][2] - 1,
@@ -1591,30 +1652,55 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     kp->nx = d->odims[0][0];
     kp->ny = d->odims[0][1];
     kp->nz = d->odims[0][2];
-    for (i = 0, j = 0; i < (int)count; i++)
-        j += d->h_keep[i] != 0;
-    if (kp_store_resize(kp, (size_t)j))
-        return SIFT3D_FAILURE;
-    for (i = 0, j = 0; i < (int)count; i++) {
-        const sift3d_hip_cand *c = d->h_cand + i;
-        const sift3d_hip_level *L = d->h_levels + c->tag;
-        keypoint_t *k;
-        size_t plane;
-        uint32_t rem;
-        if (!d->h_keep[i])
-            continue;
-        k = kp->buf + j;
-        plane = (size_t)L->nx * L->ny;
-        rem = (uint32_t)(c->idx % plane);
-        k->o = c->tag / d->ngl;
-        k->s = c->tag % d->ngl - 1;
-        k->xd = (double)(rem % (uint32_t)L->nx);
-        k->yd = (double)(rem / (uint32_t)L->nx);
-        k->zd = (double)(c->idx / plane);
-        k->sd = L->sd;
-        memcpy(k->R, d->h_R + 9 * (size_t)i, sizeof(k->R));
-        k->strength = d->h_cand[j].val;
-        j++;
+    {
+        const int nt = host_threads(count);
+        size_t pre[HOST_THREADS_MAX + 1];
+        int rc = SIFT3D_SUCCESS;
+        pre[0] = 0;
+#pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num();
+            const size_t lo = (size_t)count * t / nt, hi = (size_t)count * (t + 1) / nt;
+            size_t q, jj = 0;
+            for (q = lo; q < hi; q++)
+                jj += d->h_keep[q] != 0;
+            pre[t + 1] = jj;
+#pragma omp barrier
+#pragma omp single
+            {
+                int u;
+                for (u = 0; u < nt; u++)
+                    pre[u + 1] += pre[u];
+                rc = kp_store_resize(kp, pre[nt]);
+            }
+            /* (implicit barrier) */
+            if (rc == SIFT3D_SUCCESS) {
+                jj = pre[t];
+                for (q = lo; q < hi; q++) {
+                    const sift3d_hip_cand *c = d->h_cand + q;
+                    const sift3d_hip_level *L = d->h_levels + c->tag;
+                    keypoint_t *k;
+                    uint32_t plane, rem, zq;
+                    if (!d->h_keep[q])
+                        continue;
+                    k = kp->buf + jj;
+                    plane = (uint32_t)L->nx * (uint32_t)L->ny;      /* (a level has < 2^32 voxels) */
+                    zq = c->idx / plane;
+                    rem = c->idx - zq * plane;
+                    k->o = c->tag / d->ngl;
+                    k->s = c->tag % d->ngl - 1;
+                    k->xd = (double)(rem % (uint32_t)L->nx);
+                    k->yd = (double)(rem / (uint32_t)L->nx);
+                    k->zd = (double)zq;
+                    k->sd = L->sd;
+                    memcpy(k->R, d->h_R + 9 * q, sizeof(k->R));
+                    k->strength = d->h_cand[jj].val;
+                    jj++;
+                }
+            }
+        }
+        if (rc != SIFT3D_SUCCESS)
+            return SIFT3D_FAILURE;
     }
     d->have_pyramid = 1;
 
@@ -1682,19 +1768,32 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
         ERR("verify_keys: invalid number of keypoints: %d \n", num);
         return SIFT3D_FAILURE;
     }
-    for (i = 0; i < num; i++) {
-        const keypoint_t *k = kp->buf + i;
-        const double f = ldexp(1.0, k->o);
-        if (k->xd < 0 || k->yd < 0 || k->zd < 0 || k->xd * f >= (double)d->nx ||
-            k->yd * f >= (double)d->ny || k->zd * f >= (double)d->nz) {
-            ERR("verify_keys: keypoint %d (%f, %f, %f) octave %d exceeds image dimensions "
-                "(%d, %d, %d) \n", i, k->xd, k->yd, k->zd, k->o, d->nx, d->ny, d->nz);
-            return SIFT3D_FAILURE;
+    {
+        /* the checks on a few threads; the first offender (if any) is then reported in list order */
+        int bad = 0;
+#pragma omp parallel for num_threads(host_threads((size_t)num)) schedule(static) reduction(| : bad)
+        for (i = 0; i < num; i++) {
+            const keypoint_t *k = kp->buf + i;
+            const double f = k->o >= 0 && k->o < 64 ? (double)(1ull << k->o) : ldexp(1.0, k->o);
+            bad |= k->xd < 0 || k->yd < 0 || k->zd < 0 || k->xd * f >= (double)d->nx ||
+                   k->yd * f >= (double)d->ny || k->zd * f >= (double)d->nz || k->sd <= 0;
         }
-        if (k->sd <= 0) {
-            ERR("verify_keys: keypoint %d has invalid scale %f \n", i, k->sd);
-            return SIFT3D_FAILURE;
+        for (i = 0; i < num && bad; i++) {
+            const keypoint_t *k = kp->buf + i;
+            const double f = ldexp(1.0, k->o);
+            if (k->xd < 0 || k->yd < 0 || k->zd < 0 || k->xd * f >= (double)d->nx ||
+                k->yd * f >= (double)d->ny || k->zd * f >= (double)d->nz) {
+                ERR("verify_keys: keypoint %d (%f, %f, %f) octave %d exceeds image dimensions "
+                    "(%d, %d, %d) \n", i, k->xd, k->yd, k->zd, k->o, d->nx, d->ny, d->nz);
+                return SIFT3D_FAILURE;
+            }
+            if (k->sd <= 0) {
+                ERR("verify_keys: keypoint %d has invalid scale %f \n", i, k->sd);
+                return SIFT3D_FAILURE;
+            }
         }
+        if (bad)
+            return SIFT3D_FAILURE;       /* (a NaN coordinate: every comparison above is false) */
     }
     /* detector_has_gpyr, sift.c:1544-1549, 1623-1628 */
     if (!d->have_pyramid || !d->num_octaves) {
@@ -1725,23 +1824,48 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
         /* Launch order: widest windows first.  The window radius in level voxels grows with
          * the level index s only (14.14 * sigma0 * 2^(s/K)), and a keypoint of the last level
          * costs ~4x one of the first; longest-job-first keeps the tail of the one-wave-per-
-         * keypoint kernel short.  row1 sends every histogram to its keypoint's row. */
-        int sv, pos = 0;
-        for (sv = d->ngl - 2; sv >= -1; sv--)
-            for (i = 0; i < num; i++) {
-                const keypoint_t *k = kp->buf + i;
-                sift3d_hip_kp *q;
-                if (k->s != sv)
-                    continue;
-                q = d->h_kp + pos++;
-                memcpy(q->R, k->R, sizeof(q->R));
-                q->cx = (float)k->xd;                  /* sift.c:1474-1476 */
-                q->cy = (float)k->yd;
-                q->cz = (float)k->zd;
-                q->level = k->o * d->ngl + k->s + 1;
-                q->row1 = (uint32_t)i + 1u;
-                q->sd = k->sd;
+         * keypoint kernel short.  row1 sends every histogram to its keypoint's row.
+         * A stable counting sort by level on a few threads: per-thread counts per level, then every
+         * thread places the keypoints of its part of the list. */
+        enum { LV_MAX = 32 };
+        const int nt = host_threads((size_t)num), nlv = d->ngl;       /* s + 1 in [0, ngl) */
+        size_t cnt[HOST_THREADS_MAX][LV_MAX], start[HOST_THREADS_MAX][LV_MAX];
+        if (nlv > LV_MAX) {
+            ERR("sift3d_amd: at most %d Gaussian levels per octave are supported \n", LV_MAX);
+            return SIFT3D_FAILURE;
+        }
+        memset(cnt, 0, sizeof(cnt));
+#pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num();
+            const size_t lo = (size_t)num * t / nt, hi = (size_t)num * (t + 1) / nt;
+            size_t q;
+            for (q = lo; q < hi; q++)
+                cnt[t][kp->buf[q].s + 1]++;
+#pragma omp barrier
+#pragma omp single
+            {
+                size_t pos = 0;
+                int lv, u;
+                for (lv = nlv - 1; lv >= 0; lv--)
+                    for (u = 0; u < nt; u++) {
+                        start[u][lv] = pos;
+                        pos += cnt[u][lv];
+                    }
             }
+            /* (implicit barrier) */
+            for (q = lo; q < hi; q++) {
+                const keypoint_t *k = kp->buf + q;
+                sift3d_hip_kp *r = d->h_kp + start[t][k->s + 1]++;
+                memcpy(r->R, k->R, sizeof(r->R));
+                r->cx = (float)k->xd;                  /* sift.c:1474-1476 */
+                r->cy = (float)k->yd;
+                r->cz = (float)k->zd;
+                r->level = k->o * d->ngl + k->s + 1;
+                r->row1 = (uint32_t)q + 1u;
+                r->sd = k->sd;
+            }
+        }
     }
     /* do_extract_descriptors, sift.c:1561-1596 */
     desc->nx = d->odims[0][0];

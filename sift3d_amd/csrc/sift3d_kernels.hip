@@ -1154,6 +1154,7 @@ struct ExSweep {
     int wpr;
     uint32_t nwords;
     uint32_t *masks32;        // [3][nwords] 64-bit words as uint32 pairs
+    unsigned *exact;          // k_extrema_sweep3g<.., true>: the five max|DoG| of the octave are gathered here
 };
 
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v)
@@ -1264,7 +1265,12 @@ __global__ __launch_bounds__(256) void k_extrema_sweep3(ExSweep S)
 // centre-plane differences through an LDS tile (64 x 16 voxels + one halo row above and below,
 // loaded by 32 of the 256 threads) for the y neighbours.  One barrier per plane (the tile is
 // double-buffered).  Arithmetic, order of the tests and output are those of k_extrema_sweep3.
-template <int TXQ>
+// EST: S.absmax[] hold LOWER BOUNDS of the three maxima (k_dogmax_sub's maxima over a sub-lattice), so the
+// masks are a SUPERSET of the reference's; the sweep gathers the exact maxima of all five DoG levels over
+// its centre planes on the way (it forms every difference of those planes anyway) and
+// k_extrema_refilter then applies the reference's threshold (sift.c:829, 842) to the marked voxels.  The
+// octave's Gaussian levels are read once instead of twice.
+template <int TXQ, bool EST = false>
 __global__ __launch_bounds__(256) void k_extrema_sweep3g(ExSweep S)
 {
     constexpr int TY = 256 / TXQ;          // tile: 4 * TXQ voxels along x, TY rows
@@ -1296,6 +1302,10 @@ __global__ __launch_bounds__(256) void k_extrema_sweep3g(ExSweep S)
         okx[e] = col && y >= 1 && y <= ny - 2 && x + e >= 1 && x + e <= nx - 2;
     auto sub4 = [](const float4 &a, const float4 &b) {
         return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);   // im_subtract, imutil.c:719-739
+    };
+    float mx[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
+    auto amax4 = [](float mm, const float4 &v) {
+        return fmaxf(fmaxf(mm, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     };
     // differences 1..3 at planes z-1 (m), z (c), z+1 (p); Gaussian levels 1 and 4 at plane z
     float4 m[3], c[3], p[3], hc[3], g1c, g4c;
@@ -1374,6 +1384,14 @@ __global__ __launch_bounds__(256) void k_extrema_sweep3g(ExSweep S)
         for (int i = 0; i < 3; i++)
             p[i] = sub4(n[i], n[i + 1]);
         const float4 d0c = sub4(g0, g1c), d4c = sub4(g4c, g5);
+        if (EST && col) {
+            // (clamped duplicates of the last column / row would not matter to a maximum either)
+            mx[0] = amax4(mx[0], d0c);
+            mx[1] = amax4(mx[1], c[0]);
+            mx[2] = amax4(mx[2], c[1]);
+            mx[3] = amax4(mx[3], c[2]);
+            mx[4] = amax4(mx[4], d4c);
+        }
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const float4 pv = i == 0 ? d0c : c[i - 1], nv = i == 2 ? d4c : c[i + 1];
@@ -1423,6 +1441,75 @@ __global__ __launch_bounds__(256) void k_extrema_sweep3g(ExSweep S)
                 hc[i] = sub4(hn[i], hn[i + 1]);
         }
     }
+    if (EST) {
+        __syncthreads();                   // (block_max_atomic has a shared array of its own; the tile is done)
+        block_max_atomic<5>(mx, S.exact);
+    }
+}
+
+// max|DoG| of an octave's levels over the sub-lattice z = 1, 6, 11, ..., y = 0, 3, 6, ...: LOWER bounds of the
+// maxima (k_extrema_sweep3g<.., true> wants nothing more of them), one fifteenth of the octave's bytes.  (Strides
+// 5 and 3: a lattice point within (2, 1) voxels of every voxel, and no common factor with power-of-two
+// structure in the data.)
+constexpr int SUB_Z = 5, SUB_Y = 3;
+template <int NL>
+__global__ __launch_bounds__(256) void k_dogmax_sub(DogStack S, int nx, int ny, int nz)
+{
+    const uint32_t q = (uint32_t)nx >> 2, rpp = ((uint32_t)ny + SUB_Y - 1) / SUB_Y;
+    const uint32_t npl = nz >= 2 ? ((uint32_t)nz - 2) / SUB_Z + 1 : 1;      // planes 1, 6, ... (plane 0 if nz < 2)
+    const uint64_t items = (uint64_t)q * rpp * npl;
+    const uint64_t nthr = (uint64_t)gridDim.x * blockDim.x;
+    float m[NL - 1];
+#pragma unroll
+    for (int k = 0; k < NL - 1; k++)
+        m[k] = 0.0f;
+    for (uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += nthr) {
+        const uint32_t r = (uint32_t)(it / q), qq = (uint32_t)(it - (uint64_t)r * q);
+        const uint32_t pl = r / rpp, row = r - pl * rpp;
+        const uint32_t z = nz >= 2 ? 1 + SUB_Z * pl : 0, y = SUB_Y * row;
+        const size_t off = ((size_t)z * ny + y) * nx + 4 * qq;
+        float4 v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++)
+            v[k] = ld4(S.g[k] + off);
+#pragma unroll
+        for (int k = 0; k < NL - 1; k++) {
+            float4 r4;
+            r4.x = v[k].x - v[k + 1].x; r4.y = v[k].y - v[k + 1].y;
+            r4.z = v[k].z - v[k + 1].z; r4.w = v[k].w - v[k + 1].w;
+            m[k] = fmaxf(m[k], fmaxf(fmaxf(fabsf(r4.x), fabsf(r4.y)), fmaxf(fabsf(r4.z), fabsf(r4.w))));
+        }
+    }
+    block_max_atomic<NL - 1>(m, S.out);
+}
+
+// The masks of k_extrema_sweep3g<.., true> hold every extremum above a LOWER bound of the threshold; with
+// the exact maxima known, the reference's test (sift.c:829, 842) is applied to the marked voxels: one
+// thread per 64-voxel mask word, nearly all of them zero.
+__global__ __launch_bounds__(256) void k_extrema_refilter(ExSweep S)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (w >= (uint64_t)3 * S.nwords)
+        return;
+    unsigned long long *word = reinterpret_cast<unsigned long long *>(S.masks32) + w;
+    unsigned long long bits = *word;
+    if (!bits)
+        return;
+    const int i = (int)(w / S.nwords);
+    const uint32_t r = (uint32_t)(w - (uint64_t)i * S.nwords);
+    const uint32_t rowi = r / (uint32_t)S.wpr, wc = r - rowi * (uint32_t)S.wpr;   // rowi = z * ny + y
+    const size_t base = (size_t)rowi * S.nx + 64u * wc;
+    const float thr = (float)(S.peak_thresh * (double)__uint_as_float(S.exact[1 + i]));    // sift.c:829
+    const float *ga = S.d[i + 1], *gb = S.d[i + 2];
+    unsigned long long keep = bits;
+    while (bits) {
+        const int b = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        const float v = ga[base + b] - gb[base + b];                               // im_subtract
+        if (!((v > thr) | (v < -thr)))                                             // sift.c:842
+            keep &= ~(1ull << b);
+    }
+    *word = keep;
 }
 
 // candidates per block of EX_WPB mask words (what k_extrema_mask counts itself)
@@ -1445,36 +1532,38 @@ __global__ __launch_bounds__(256) void k_extrema_count(const unsigned long long 
         blk_counts[(size_t)level * nblk + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
 
-// exclusive scan of the block counts (all levels of the launch), continuing from *d_count
+// exclusive scan of the block counts (all levels of the launch), continuing from *d_count.  One workgroup:
+// every thread adds up a contiguous run of entries, the 1024 run sums are scanned across the workgroup, and
+// every thread writes its run's exclusive prefixes (49 152 entries at 512^3: 48 per thread -- the chunked
+// Hillis-Steele scan this replaces took 480 barriers and 85 us there).
 __global__ __launch_bounds__(1024) void k_extrema_scan(uint32_t *__restrict__ blk, uint32_t n,
                                                        uint32_t *__restrict__ d_count)
 {
     __shared__ uint32_t part[1024];
-    __shared__ uint32_t carry;
     const int t = threadIdx.x;
-    if (t == 0)
-        carry = *d_count;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = min(n, (uint32_t)t * per), hi = min(n, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++)
+        sum += blk[i];
+    part[t] = sum;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + t;
-        const uint32_t v = i < n ? blk[i] : 0;
-        part[t] = v;
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t add = t >= o ? part[t - o] : 0;
         __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const uint32_t add = t >= o ? part[t - o] : 0;
-            __syncthreads();
-            part[t] += add;
-            __syncthreads();
-        }
-        if (i < n)
-            blk[i] = carry + part[t] - v;
-        __syncthreads();
-        if (t == 0)
-            carry += part[1023];
+        part[t] += add;
         __syncthreads();
     }
-    if (t == 0)
-        *d_count = carry;
+    const uint32_t carry = *d_count;
+    uint32_t run = carry + part[t] - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = blk[i];
+        blk[i] = run;
+        run += v;
+    }
+    __syncthreads();                       // (every thread has read *d_count)
+    if (t == 1023)
+        *d_count = carry + part[1023];
 }
 
 // FROM_G: `cur` and `next` of a level hold the two Gaussian levels whose difference is the DoG
@@ -1491,18 +1580,35 @@ __global__ __launch_bounds__(256) void k_extrema_emit(ExLevels LV, ExGeom E,
     const sift3d_hip_extrema_level L = LV.lv[level];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t w0 = blockIdx.x * EX_WPB;
-    if (threadIdx.x < EX_WPB) {
+    // pre[i] = candidates in the block's words before word i: the first EX_WPB / 64 waves hold one word per
+    // lane, scan their counts by wave shifts and add the totals of the waves before them
+    static_assert(EX_WPB % 64 == 0 && EX_WPB <= 256, "one word per thread of the first waves");
+    __shared__ uint32_t wtot[EX_WPB / 64];
+    {
         const uint32_t word = w0 + threadIdx.x;
-        pre[threadIdx.x + 1] =
-            word < E.nwords ? (uint32_t)__popcll(masks[(size_t)level * E.nwords + word]) : 0;
+        uint32_t inc = threadIdx.x < EX_WPB && word < E.nwords
+                           ? (uint32_t)__popcll(masks[(size_t)level * E.nwords + word]) : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(inc, o, 64);
+            inc += lane >= o ? v : 0;
+        }
+        if (threadIdx.x < EX_WPB) {
+            pre[threadIdx.x + 1] = inc;
+            if (lane == 63)
+                wtot[wave] = inc;
+        }
+        if (threadIdx.x == 0)
+            pre[0] = 0;
+        __syncthreads();
+        if (threadIdx.x >= 64 && threadIdx.x < EX_WPB) {
+            uint32_t add = 0;
+            for (int u = 0; u < wave; u++)
+                add += wtot[u];
+            pre[threadIdx.x + 1] += add;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        pre[0] = 0;
-        for (int i = 1; i <= EX_WPB; i++)
-            pre[i] += pre[i - 1];
-    }
-    __syncthreads();
     if (pre[EX_WPB] == 0)
         return;
     const uint32_t base = blk_off[(size_t)level * E.nblk + blockIdx.x];
@@ -2919,12 +3025,64 @@ int sift3d_hip_extrema_gauss6(const float *const *d_g, const float *d_absmax, in
                                            cap, d_count, d_work, work_bytes, stream, 0);
 }
 
+// Lower bounds of an octave's five max|DoG| from a sub-lattice of its six Gaussian levels (one fifteenth of the
+// bytes), atomically maxed into d_est[0..4] (zeroed by the caller): what sift3d_hip_extrema_gauss6_est_phase
+// thresholds its sweep with.  1: not covered.
+int sift3d_hip_dogmax_sub(const float *const *d_g, int nx, int ny, int nz, float *d_est, void *stream)
+{
+    if ((nx & 3) || nx < 4 || ny < 1 || nz < 1)
+        return 1;
+    DogStack S;
+    memset(&S, 0, sizeof(S));
+    for (int k = 0; k < 6; k++) {
+        S.g[k] = d_g[k];
+        if ((uintptr_t)d_g[k] & 15)
+            return 1;
+    }
+    S.out = reinterpret_cast<unsigned *>(d_est);
+    const size_t items = (size_t)(nx / 4) * ((ny + SUB_Y - 1) / SUB_Y) * (nz >= 2 ? (nz - 2) / SUB_Z + 1 : 1);
+    hipLaunchKernelGGL((k_dogmax_sub<6>), dim3(grid_reduce(4 * items)), dim3(256), 0, (hipStream_t)stream, S, nx,
+                       ny, nz);
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+static int extrema_gauss6_impl(const float *const *d_g, const float *d_absmax, const float *d_est,
+                               float *d_exact, int nx, int ny, int nz, int z_lo, int z_hi, int tag0,
+                               double peak_thresh, sift3d_hip_cand *d_out, uint32_t cap, uint32_t *d_count,
+                               void *d_work, size_t work_bytes, void *stream, int phase);
+
 // phase 1: the sweep (masks + per-block counts in d_work; independent of every other octave);
 // phase 2: scan + emission, which appends to d_out at *d_count (so: in octave order); 0: both
 int sift3d_hip_extrema_gauss6_phase(const float *const *d_g, const float *d_absmax, int nx, int ny, int nz,
                                     int z_lo, int z_hi, int tag0, double peak_thresh,
                                     sift3d_hip_cand *d_out, uint32_t cap, uint32_t *d_count, void *d_work,
                                     size_t work_bytes, void *stream, int phase)
+{
+    return extrema_gauss6_impl(d_g, d_absmax, nullptr, nullptr, nx, ny, nz, z_lo, z_hi, tag0, peak_thresh, d_out,
+                               cap, d_count, d_work, work_bytes, stream, phase);
+}
+
+// The same stage WITHOUT a separate pass for the maxima: d_est[0..4] are lower bounds of the octave's
+// max|DoG| (sift3d_hip_dogmax_sub), the sweep marks every extremum above peak_thresh * bound and gathers the
+// exact maxima into d_exact[0..4] (zeroed by the caller before phase 1; the two planes the sweep has no
+// centre on are added by two one-plane launches), and the reference's threshold is then applied to the
+// marked voxels.  Whole volumes only (z_lo = 1, z_hi = nz - 1: the maxima are those of the planes swept).
+int sift3d_hip_extrema_gauss6_est_phase(const float *const *d_g, const float *d_est, float *d_exact, int nx,
+                                        int ny, int nz, int tag0, double peak_thresh, sift3d_hip_cand *d_out,
+                                        uint32_t cap, uint32_t *d_count, void *d_work, size_t work_bytes,
+                                        void *stream, int phase)
+{
+    if (!d_est || !d_exact)
+        return SIFT3D_FAILURE;
+    return extrema_gauss6_impl(d_g, d_exact, d_est, d_exact, nx, ny, nz, 1, nz - 1, tag0, peak_thresh, d_out, cap,
+                               d_count, d_work, work_bytes, stream, phase);
+}
+
+static int extrema_gauss6_impl(const float *const *d_g, const float *d_absmax, const float *d_est,
+                               float *d_exact, int nx, int ny, int nz, int z_lo, int z_hi, int tag0,
+                               double peak_thresh, sift3d_hip_cand *d_out, uint32_t cap, uint32_t *d_count,
+                               void *d_work, size_t work_bytes, void *stream, int phase)
 {
     hipStream_t st = (hipStream_t)stream;
     if ((size_t)nx * ny * nz >= (1ull << 32) || work_bytes < sift3d_hip_extrema_work_bytes(nx, ny, nz, 3)) {
@@ -2946,7 +3104,8 @@ int sift3d_hip_extrema_gauss6_phase(const float *const *d_g, const float *d_absm
     for (int i = 0; i < 6; i++)
         S.d[i] = d_g[i];
     for (int i = 0; i < 3; i++)
-        S.absmax[i] = d_absmax + 1 + i;       // DoG levels 1..3 are the keypoint levels
+        S.absmax[i] = (d_est ? d_est : d_absmax) + 1 + i;       // DoG levels 1..3 are the keypoint levels
+    S.exact = reinterpret_cast<unsigned *>(d_exact);
     S.peak_thresh = peak_thresh;
     S.nx = nx; S.ny = ny; S.nz = nz;
     S.z_lo = z_lo; S.z_hi = z_hi;
@@ -2966,12 +3125,33 @@ int sift3d_hip_extrema_gauss6_phase(const float *const *d_g, const float *d_absm
         nseg = nseg < cap_seg ? nseg : cap_seg;
         S.ts = (int)((n_out + nseg - 1) / nseg);
         dim3 grid((nx + 4 * txq - 1) / (4 * txq), (ny + tyy - 1) / tyy, (n_out + S.ts - 1) / S.ts);
-        if (txq == 32)
-            hipLaunchKernelGGL(k_extrema_sweep3g<32>, grid, dim3(256), 0, st, S);
+        if (d_est) {
+            if (txq == 32)
+                hipLaunchKernelGGL((k_extrema_sweep3g<32, true>), grid, dim3(256), 0, st, S);
+            else if (txq == 64)
+                hipLaunchKernelGGL((k_extrema_sweep3g<64, true>), grid, dim3(256), 0, st, S);
+            else
+                hipLaunchKernelGGL((k_extrema_sweep3g<16, true>), grid, dim3(256), 0, st, S);
+        } else if (txq == 32)
+            hipLaunchKernelGGL((k_extrema_sweep3g<32>), grid, dim3(256), 0, st, S);
         else if (txq == 64)
-            hipLaunchKernelGGL(k_extrema_sweep3g<64>, grid, dim3(256), 0, st, S);
+            hipLaunchKernelGGL((k_extrema_sweep3g<64>), grid, dim3(256), 0, st, S);
         else
-            hipLaunchKernelGGL(k_extrema_sweep3g<16>, grid, dim3(256), 0, st, S);
+            hipLaunchKernelGGL((k_extrema_sweep3g<16>), grid, dim3(256), 0, st, S);
+    }
+    if (d_est && phase != 2) {
+        // the first and the last plane, then the reference's threshold on the marked voxels
+        const size_t plane = (size_t)nx * ny;
+        const float *g0[6], *g1[6];
+        for (int i = 0; i < 6; i++) {
+            g0[i] = d_g[i];
+            g1[i] = d_g[i] + (size_t)(nz - 1) * plane;
+        }
+        if (sift3d_hip_dogmax_stack(g0, 6, plane, d_exact, stream) != SIFT3D_SUCCESS ||
+            sift3d_hip_dogmax_stack(g1, 6, plane, d_exact, stream) != SIFT3D_SUCCESS)
+            return SIFT3D_FAILURE;
+        hipLaunchKernelGGL(k_extrema_refilter, dim3((unsigned)(((size_t)3 * E.nwords + 255) / 256)), dim3(256), 0,
+                           st, S);
     }
     if (phase != 2)
         hipLaunchKernelGGL(k_extrema_count, dim3(E.nblk, 3), dim3(256), 0, st, masks, E.nwords, E.nblk, blk);

@@ -511,6 +511,38 @@ def test_orientation_parallel_sums_equal_serial_sums(gpu, oracle_mod, case):
         np.testing.assert_array_equal(got[0][1][f], got[1][1][f], err_msg=f)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["lattice160", "noise96", "spike128", "aniso"])
+def test_dogmax_gathered_by_the_sweep_equals_its_own_pass(gpu, oracle_mod, case):
+    """Octave 0's dogmax scan (sift.c:821-826) has no pass of its own by default: the extrema sweep is
+    thresholded with LOWER bounds from a sub-lattice, gathers the exact maxima and the reference's threshold
+    is applied to the marked voxels afterwards (sift3d_hip_extrema_gauss6_est_phase).  Maxima, candidates
+    and keypoints must be those of the two-pass path -- also when the sub-lattice misses the maximum by far
+    (spike128: one voxel off the sub-lattice carries it, so the sweep marks nearly every extremum)."""
+    api, hip, torch = gpu
+    units, kw = (1.0, 1.0, 1.0), {}
+    if case == "lattice160":
+        vol = oracle_mod.synth_lattice(160, seed=21)
+    elif case == "noise96":
+        vol = np.random.default_rng(3).standard_normal((96, 96, 96)).astype(np.float32)
+    elif case == "spike128":
+        vol = np.random.default_rng(4).random((128, 128, 128), dtype=np.float32)
+        vol[65, 33, 77] = 400.0            # (z, y, x): z % 3 != 1, y odd
+    else:
+        vol, units = oracle_mod.synth_survey((72, 60, 80)), (1.0, 1.5, 0.7)
+    got = {}
+    for own_pass in (True, False):
+        det, kp = api.Detector(**kw), api.KeypointStore()
+        assert det.set_dogmax_pass(own_pass) == 0
+        assert det.detect_keypoints(api.Image.from_array(vol, units=units), kp) == 0
+        got[own_pass] = (det.num_candidates(), kp.records(), det.dogmax())
+    assert got[True][0] == got[False][0] and len(got[True][1]) == len(got[False][1])
+    np.testing.assert_array_equal(got[True][2], got[False][2])
+    assert (got[True][2] > 0).all()
+    for f in ("o", "s", "xd", "yd", "zd", "sd", "strength", "R"):
+        np.testing.assert_array_equal(got[True][1][f], got[False][1][f], err_msg=f)
+
+
 def test_repeated_runs_are_bitwise_identical(gpu):
     """The window kernels rely on the issue order of a wave's LDS operations and on block-level
     reductions through atomicMax only: every run must give the same bits."""
