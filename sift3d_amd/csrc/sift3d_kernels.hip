@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(256) void k_extrema_sweep3(ExSweep S)
 // k_extrema_refilter then applies the reference's threshold (sift.c:829, 842) to the marked voxels.  The
 // octave's Gaussian levels are read once instead of twice.
 template <int TXQ, bool EST = false>
-__global__ __launch_bounds__(256) void k_extrema_sweep3g(ExSweep S)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_extrema_sweep3g(ExSweep S)
 {
     constexpr int TY = 256 / TXQ;          // tile: 4 * TXQ voxels along x, TY rows
     __shared__ float4 tile[2][3][TY + 2][TXQ];
@@ -1532,38 +1532,76 @@ __global__ __launch_bounds__(256) void k_extrema_count(const unsigned long long 
         blk_counts[(size_t)level * nblk + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
 
-// exclusive scan of the block counts (all levels of the launch), continuing from *d_count.  One workgroup:
-// every thread adds up a contiguous run of entries, the 1024 run sums are scanned across the workgroup, and
-// every thread writes its run's exclusive prefixes (49 152 entries at 512^3: 48 per thread -- the chunked
-// Hillis-Steele scan this replaces took 480 barriers and 85 us there).
+// exclusive scan of the block counts (all levels of the launch), continuing from *d_count.  One workgroup
+// walks the array in chunks of 8192 entries: a thread loads eight consecutive entries (two 16-byte loads,
+// coalesced), scans them, the thread sums are scanned by wave shifts and the sixteen wave totals by the
+// first wave -- two barriers per chunk (49 152 entries at 512^3: 6 chunks; the chunked Hillis-Steele scan
+// this replaces took 480 barriers and 85 us there).
 __global__ __launch_bounds__(1024) void k_extrema_scan(uint32_t *__restrict__ blk, uint32_t n,
                                                        uint32_t *__restrict__ d_count)
 {
-    __shared__ uint32_t part[1024];
-    const int t = threadIdx.x;
-    const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t lo = min(n, (uint32_t)t * per), hi = min(n, lo + per);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; i++)
-        sum += blk[i];
-    part[t] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const uint32_t add = t >= o ? part[t - o] : 0;
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t wsum;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    uint32_t carry = *d_count;
+    for (uint32_t base = 0; base < n; base += 8192) {
+        const uint32_t i0 = base + 8u * (uint32_t)t;
+        uint32_t v[8];
+        if (i0 + 8 <= n && (((uintptr_t)(blk + i0)) & 15) == 0) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(blk + i0), b = *reinterpret_cast<const uint4 *>(blk + i0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                v[k] = i0 + k < n ? blk[i0 + k] : 0;
+        }
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            sum += v[k];
+        uint32_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(inc, o, 64);
+            inc += lane >= o ? u : 0;
+        }
+        if (lane == 63)
+            wtot[wave] = inc;
         __syncthreads();
-        part[t] += add;
+        if (wave == 0) {
+            uint32_t w = lane < 16 ? wtot[lane] : 0, winc = w;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const uint32_t u = __shfl_up(winc, o, 64);
+                winc += lane >= o ? u : 0;
+            }
+            if (lane < 16)
+                wtot[lane] = winc - w;                 // exclusive
+            if (lane == 15)
+                wsum = winc;
+        }
         __syncthreads();
+        uint32_t run = carry + wtot[wave] + inc - sum;
+        carry += wsum;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t x = v[k];
+            v[k] = run;
+            run += x;
+        }
+        if (i0 + 8 <= n && (((uintptr_t)(blk + i0)) & 15) == 0) {
+            *reinterpret_cast<uint4 *>(blk + i0) = make_uint4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<uint4 *>(blk + i0 + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (i0 + k < n)
+                    blk[i0 + k] = v[k];
+        }
+        __syncthreads();                   // wtot / wsum are rewritten by the next chunk
     }
-    const uint32_t carry = *d_count;
-    uint32_t run = carry + part[t] - sum;
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t v = blk[i];
-        blk[i] = run;
-        run += v;
-    }
-    __syncthreads();                       // (every thread has read *d_count)
-    if (t == 1023)
-        *d_count = carry + part[1023];
+    if (t == 0)
+        *d_count = carry;
 }
 
 // FROM_G: `cur` and `next` of a level hold the two Gaussian levels whose difference is the DoG
@@ -1618,16 +1656,16 @@ __global__ __launch_bounds__(256) void k_extrema_emit(ExLevels LV, ExGeom E,
     unsigned long long mine = 0ull;
     if (lane < EX_WPB / 4 && w0 + wave * (EX_WPB / 4) + lane < E.nwords)
         mine = masks[(size_t)level * E.nwords + w0 + wave * (EX_WPB / 4) + lane];
-    for (int w = 0; w < EX_WPB / 4; w++) {
+    // only the words that hold a candidate (a few per cent of them) are visited
+    unsigned long long todo = __ballot(mine != 0ull);
+    while (todo) {
+        const int w = __ffsll((long long)todo) - 1;          // wave-uniform
+        todo &= todo - 1ull;
         const int wi = wave * (EX_WPB / 4) + w;
         const uint32_t word = w0 + wi;
-        if (word >= E.nwords)
-            break;
         const unsigned long long m =
             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), w) << 32) |
             (unsigned)__builtin_amdgcn_readlane((int)mine, w);
-        if (m == 0ull)
-            continue;   // wave-uniform
         if (!((m >> lane) & 1ull))
             continue;
         const uint32_t pos = base + pre[wi] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
