@@ -554,7 +554,7 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
 {
     const double t_start = now_s();
     uint32_t count = 0;
-    int o, s, r, i, k, attempt, nkey, all_free = 1;
+    int o, s, r, k, attempt, nkey, all_free = 1;
     if (!S || !kp)
         return SIFT3D_FAILURE;
     nkey = S->num_octaves * S->K;
@@ -800,19 +800,40 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
         int32_t *cnt = (int32_t *)calloc((size_t)nkey * 2, sizeof(int32_t));
         int32_t *allcnt;
         int64_t *cc, *ck;            /* per rank prefix sums over keys: candidates / kept */
-        size_t nkept = 0, maxc = 0, maxk = 0, tot_c = 0, tot_k = 0, j;
+        size_t *segstart = NULL;     /* first global position of segment (key, rank) */
+        size_t nkept = 0, maxc = 0, maxk = 0, tot_c = 0, tot_k = 0;
         float *vals;
         sh_gkp *recs;
         if (!cnt)
             return SIFT3D_FAILURE;
-        for (i = 0; i < (int)count; i++) {
-            const int tag = S->h_cand[i].tag;
-            const int key = (tag / S->ngl) * S->K + (tag % S->ngl - 1);
-            cnt[2 * key]++;
-            if (S->h_keep[i]) {
-                cnt[2 * key + 1]++;
-                nkept++;
+        /* (the host loops over the candidate and keypoint lists run on a few threads, each on a contiguous
+         * part of the list: the order of the records is the reference's scan order and is kept) */
+        {
+            const int nt = host_threads(count);
+            int32_t *tc = (int32_t *)calloc((size_t)nt * 2 * (size_t)nkey, sizeof(int32_t));
+            if (!tc) {
+                free(cnt);
+                return SIFT3D_FAILURE;
             }
+#pragma omp parallel num_threads(nt)
+            {
+                const int t = omp_get_thread_num();
+                const size_t lo = (size_t)count * t / nt, hi = (size_t)count * (t + 1) / nt;
+                int32_t *mine = tc + (size_t)t * 2 * nkey;
+                size_t q;
+                for (q = lo; q < hi; q++) {
+                    const int tag = S->h_cand[q].tag;
+                    const int key = (tag / S->ngl) * S->K + (tag % S->ngl - 1);
+                    mine[2 * key]++;
+                    mine[2 * key + 1] += S->h_keep[q] != 0;
+                }
+            }
+            for (r = 0; r < nt; r++)
+                for (k = 0; k < 2 * nkey; k++)
+                    cnt[k] += tc[(size_t)r * 2 * nkey + k];
+            for (k = 0; k < nkey; k++)
+                nkept += (size_t)cnt[2 * k + 1];
+            free(tc);
         }
         if (sh_allgather_host(S, cnt, sizeof(int32_t) * 2 * (size_t)nkey)) {
             free(cnt);
@@ -824,8 +845,9 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
             allcnt = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)nkey * S->world);
             cc = (int64_t *)calloc((size_t)(nkey + 1) * S->world, sizeof(int64_t));
             ck = (int64_t *)calloc((size_t)(nkey + 1) * S->world, sizeof(int64_t));
-            if (!allcnt || !cc || !ck) {
-                free(allcnt); free(cc); free(ck);
+            segstart = (size_t *)calloc((size_t)nkey * S->world + 1, sizeof(size_t));
+            if (!allcnt || !cc || !ck || !segstart) {
+                free(allcnt); free(cc); free(ck); free(segstart);
                 return SIFT3D_FAILURE;
             }
             for (r = 0; r < S->world; r++) {
@@ -846,70 +868,115 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
         recs = (sh_gkp *)calloc(maxk ? maxk : 1, sizeof(sh_gkp));
         vals = (float *)calloc(maxc ? maxc : 1, sizeof(float));
         if (!recs || !vals) {
-            free(recs); free(vals); free(allcnt); free(cc); free(ck);
+            free(recs); free(vals); free(allcnt); free(cc); free(ck); free(segstart);
             return SIFT3D_FAILURE;
         }
-        for (i = 0, j = 0; i < (int)count; i++) {
-            const sift3d_hip_cand *c = S->h_cand + i;
-            const int oo = c->tag / S->ngl;
-            const size_t plane = sh_plane(S, oo);
-            const uint32_t rem = (uint32_t)(c->idx % plane);
-            vals[i] = c->val;
-            if (!S->h_keep[i])
-                continue;
-            recs[j].o = oo;
-            recs[j].s = c->tag % S->ngl - 1;
-            recs[j].x = (int32_t)(rem % (uint32_t)S->dims[oo][0]);
-            recs[j].y = (int32_t)(rem / (uint32_t)S->dims[oo][0]);
-            recs[j].z = (int32_t)(c->idx / plane) + S->G[oo][0].off;
-            memcpy(recs[j].R, S->h_R + 9 * (size_t)i, sizeof(recs[j].R));
-            j++;
+        {
+            const int nt = host_threads(count);
+            size_t pre[HOST_THREADS_MAX + 1];
+            pre[0] = 0;
+#pragma omp parallel num_threads(nt)
+            {
+                const int t = omp_get_thread_num();
+                const size_t lo = (size_t)count * t / nt, hi = (size_t)count * (t + 1) / nt;
+                size_t q, jj = 0;
+                for (q = lo; q < hi; q++)
+                    jj += S->h_keep[q] != 0;
+                pre[t + 1] = jj;
+#pragma omp barrier
+#pragma omp single
+                {
+                    int u;
+                    for (u = 0; u < nt; u++)
+                        pre[u + 1] += pre[u];
+                }
+                /* (implicit barrier) */
+                jj = pre[t];
+                for (q = lo; q < hi; q++) {
+                    const sift3d_hip_cand *c = S->h_cand + q;
+                    const int oo = c->tag / S->ngl;
+                    const uint32_t plane = (uint32_t)sh_plane(S, oo);        /* (a level has < 2^32 voxels) */
+                    const uint32_t zq = c->idx / plane, rem = c->idx - zq * plane;
+                    vals[q] = c->val;
+                    if (!S->h_keep[q])
+                        continue;
+                    recs[jj].o = oo;
+                    recs[jj].s = c->tag % S->ngl - 1;
+                    recs[jj].x = (int32_t)(rem % (uint32_t)S->dims[oo][0]);
+                    recs[jj].y = (int32_t)(rem / (uint32_t)S->dims[oo][0]);
+                    recs[jj].z = (int32_t)zq + S->G[oo][0].off;
+                    memcpy(recs[jj].R, S->h_R + 9 * q, sizeof(recs[jj].R));
+                    jj++;
+                }
+            }
         }
         /* keypoint store: dimensions of the first octave (sift.c:756-759) */
         kp->nx = S->nx; kp->ny = S->ny; kp->nz = S->nz;
         if (kp_store_resize(kp, tot_k)) {
-            free(recs); free(vals); free(allcnt); free(cc); free(ck);
+            free(recs); free(vals); free(allcnt); free(cc); free(ck); free(segstart);
             return SIFT3D_FAILURE;
         }
         /* values first (the staging buffer is reused): copy_Keypoint omits `strength`
          * (sift.c:372-384), so slot j keeps GLOBAL candidate j's value (quirk Q2): only the first
          * tot_k values of the global candidate order matter */
         if (sh_allgather_host(S, vals, sizeof(float) * (maxc ? maxc : 1))) {
-            free(recs); free(vals); free(allcnt); free(cc); free(ck);
+            free(recs); free(vals); free(allcnt); free(cc); free(ck); free(segstart);
             return SIFT3D_FAILURE;
         }
         {
+            /* segment (k, r) of the global candidate order starts at cstart[k * world + r] */
             const size_t pad = (sizeof(float) * (maxc ? maxc : 1) + 15) & ~(size_t)15;
+            const int nseg = nkey * S->world;
+            int sg;
             size_t got = 0;
-            for (k = 0; k < nkey && got < tot_k; k++)
-                for (r = 0; r < S->world && got < tot_k; r++) {
-                    const float *v = (const float *)((char *)S->h_xchg + pad * (S->world == 1 ? 0 : r));
-                    int64_t q;
-                    for (q = cc[(size_t)r * (nkey + 1) + k]; q < cc[(size_t)r * (nkey + 1) + k + 1] && got < tot_k; q++)
-                        kp->buf[got++].strength = v[q];
+            for (k = 0; k < nkey; k++)
+                for (r = 0; r < S->world; r++) {
+                    segstart[(size_t)k * S->world + r] = got;
+                    got += (size_t)(cc[(size_t)r * (nkey + 1) + k + 1] - cc[(size_t)r * (nkey + 1) + k]);
                 }
+#pragma omp parallel for num_threads(host_threads(tot_k)) schedule(dynamic, 1)
+            for (sg = 0; sg < nseg; sg++) {
+                const int kk_ = sg / S->world, rr = sg % S->world;
+                const float *v = (const float *)((char *)S->h_xchg + pad * (S->world == 1 ? 0 : rr));
+                const int64_t q0 = cc[(size_t)rr * (nkey + 1) + kk_], q1 = cc[(size_t)rr * (nkey + 1) + kk_ + 1];
+                size_t g = segstart[sg];
+                int64_t q;
+                for (q = q0; q < q1 && g < tot_k; q++)
+                    kp->buf[g++].strength = v[q];
+            }
         }
         if (sh_allgather_host(S, recs, sizeof(sh_gkp) * (maxk ? maxk : 1))) {
-            free(recs); free(vals); free(allcnt); free(cc); free(ck);
+            free(recs); free(vals); free(allcnt); free(cc); free(ck); free(segstart);
             return SIFT3D_FAILURE;
         }
         {
             const size_t pad = (sizeof(sh_gkp) * (maxk ? maxk : 1) + 15) & ~(size_t)15;
+            const int nseg = nkey * S->world;
+            int sg;
             size_t got = 0;
             for (k = 0; k < nkey; k++)
                 for (r = 0; r < S->world; r++) {
-                    const sh_gkp *g = (const sh_gkp *)((char *)S->h_xchg + pad * (S->world == 1 ? 0 : r));
-                    int64_t q;
-                    for (q = ck[(size_t)r * (nkey + 1) + k]; q < ck[(size_t)r * (nkey + 1) + k + 1]; q++) {
-                        keypoint_t *kk = kp->buf + got++;
-                        kk->o = g[q].o; kk->s = g[q].s;
-                        kk->xd = g[q].x; kk->yd = g[q].y; kk->zd = g[q].z;
-                        kk->sd = sh_scale(S, g[q].o, g[q].s);
-                        memcpy(kk->R, g[q].R, sizeof(kk->R));
-                    }
+                    segstart[(size_t)k * S->world + r] = got;
+                    got += (size_t)(ck[(size_t)r * (nkey + 1) + k + 1] - ck[(size_t)r * (nkey + 1) + k]);
                 }
+#pragma omp parallel for num_threads(host_threads(tot_k)) schedule(dynamic, 1)
+            for (sg = 0; sg < nseg; sg++) {
+                const int kk_ = sg / S->world, rr = sg % S->world;
+                const sh_gkp *g = (const sh_gkp *)((char *)S->h_xchg + pad * (S->world == 1 ? 0 : rr));
+                const int64_t q0 = ck[(size_t)rr * (nkey + 1) + kk_], q1 = ck[(size_t)rr * (nkey + 1) + kk_ + 1];
+                /* a segment holds one (octave, level): one scale (imutil.c:1578-1579) */
+                const double sd = sh_scale(S, kk_ / S->K, kk_ % S->K);
+                keypoint_t *kk = kp->buf + segstart[sg];
+                int64_t q;
+                for (q = q0; q < q1; q++, kk++) {
+                    kk->o = g[q].o; kk->s = g[q].s;
+                    kk->xd = g[q].x; kk->yd = g[q].y; kk->zd = g[q].z;
+                    kk->sd = sd;
+                    memcpy(kk->R, g[q].R, sizeof(kk->R));
+                }
+            }
         }
-        free(recs); free(vals); free(allcnt); free(cc); free(ck);
+        free(recs); free(vals); free(allcnt); free(cc); free(ck); free(segstart);
     }
     S->t[0] = 1e-3 * sift3d_hip_event_elapsed_ms(S->ev0, S->ev1);
     S->t[3] = 1e-3 * sift3d_hip_event_elapsed_ms(S->ev1, S->ev2);
@@ -928,17 +995,54 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
                                 sift3d_descriptor_store *desc, int *own_idx, int *n_own)
 {
     const double t_start = now_s();
-    int i, n = 0, sv, pos = 0, num;
+    int n = 0, num;
     if (!S || !kp || !desc || !own_idx || !n_own)
         return SIFT3D_FAILURE;
     num = (int)kp->num;
-    for (i = 0; i < num; i++) {
-        const keypoint_t *k = kp->buf + i;
-        if (k->o < 0 || k->o >= S->num_octaves || k->s < 0 || k->s >= S->K)
+    {
+        /* the keypoints this rank owns, in list order: counted and placed by a few threads, each on a
+         * contiguous part of the list */
+        const int nt = host_threads((size_t)num);
+        size_t pre[HOST_THREADS_MAX + 1];
+        int bad = 0;
+        pre[0] = 0;
+#pragma omp parallel num_threads(nt) reduction(| : bad)
+        {
+            const int t = omp_get_thread_num();
+            const size_t lo = (size_t)num * t / nt, hi = (size_t)num * (t + 1) / nt;
+            size_t q, jj = 0;
+#define SH_OWN(k_) (S->world == 1 || ((k_)->zd >= (double)S->bounds[(k_)->o][S->rank] &&          \
+                                      (k_)->zd < (double)S->bounds[(k_)->o][S->rank + 1]))
+            for (q = lo; q < hi; q++) {
+                const keypoint_t *k = kp->buf + q;
+                if (k->o < 0 || k->o >= S->num_octaves || k->s < 0 || k->s >= S->K) {
+                    bad = 1;
+                    continue;
+                }
+                jj += SH_OWN(k) ? 1 : 0;
+            }
+            pre[t + 1] = jj;
+#pragma omp barrier
+#pragma omp single
+            {
+                int u;
+                for (u = 0; u < nt; u++)
+                    pre[u + 1] += pre[u];
+            }
+            /* (implicit barrier) */
+            jj = pre[t];
+            for (q = lo; q < hi; q++) {
+                const keypoint_t *k = kp->buf + q;
+                if (k->o < 0 || k->o >= S->num_octaves || k->s < 0 || k->s >= S->K)
+                    continue;
+                if (SH_OWN(k))
+                    own_idx[jj++] = (int)q;
+            }
+#undef SH_OWN
+        }
+        if (bad)
             return SIFT3D_FAILURE;
-        if (S->world == 1 || (k->zd >= (double)S->bounds[k->o][S->rank] &&
-                              k->zd < (double)S->bounds[k->o][S->rank + 1]))
-            own_idx[n++] = i;
+        n = (int)pre[nt];
     }
     *n_own = n;
     desc->nx = S->nx; desc->ny = S->ny; desc->nz = S->nz;
@@ -969,27 +1073,49 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
             return SIFT3D_FAILURE;
         S->kp_cap = cap;
     }
-    /* launch order: widest windows first, each histogram to its own row */
-    for (sv = S->K - 1; sv >= 0; sv--)
-        for (i = 0; i < n; i++) {
-            const keypoint_t *k = kp->buf + own_idx[i];
-            sift3d_hip_kp *q;
-            if (k->s != sv)
-                continue;
-            q = S->h_kp + pos++;
-            memcpy(q->R, k->R, sizeof(q->R));
-            q->cx = (float)k->xd; q->cy = (float)k->yd; q->cz = (float)k->zd;   /* sift.c:1474-1476 */
-            q->level = k->o * S->ngl + k->s + 1;
-            q->row1 = (uint32_t)i + 1u;
-            q->sd = k->sd;
+    /* launch order: widest windows first, each histogram to its own row (a stable counting sort by level,
+     * as in sift3d_extract_descriptors) */
+    {
+        enum { LVM = 16 };
+        const int nt = host_threads((size_t)n);
+        size_t cnt[HOST_THREADS_MAX][LVM], start[HOST_THREADS_MAX][LVM];
+        if (S->K > LVM)
+            return SIFT3D_FAILURE;
+        memset(cnt, 0, sizeof(cnt));
+#pragma omp parallel num_threads(nt)
+        {
+            const int t = omp_get_thread_num();
+            const size_t lo = (size_t)n * t / nt, hi = (size_t)n * (t + 1) / nt;
+            size_t q;
+            for (q = lo; q < hi; q++)
+                cnt[t][kp->buf[own_idx[q]].s]++;
+#pragma omp barrier
+#pragma omp single
+            {
+                size_t p = 0;
+                int lv, u;
+                for (lv = S->K - 1; lv >= 0; lv--)
+                    for (u = 0; u < nt; u++) {
+                        start[u][lv] = p;
+                        p += cnt[u][lv];
+                    }
+            }
+            /* (implicit barrier) */
+            for (q = lo; q < hi; q++) {
+                const keypoint_t *k = kp->buf + own_idx[q];
+                const double f = ldexp(1.0, k->o);                 /* sift.c:1459, 1530-1533 */
+                sift3d_hip_kp *r = S->h_kp + start[t][k->s]++;
+                memcpy(r->R, k->R, sizeof(r->R));
+                r->cx = (float)k->xd; r->cy = (float)k->yd; r->cz = (float)k->zd;   /* sift.c:1474-1476 */
+                r->level = k->o * S->ngl + k->s + 1;
+                r->row1 = (uint32_t)q + 1u;
+                r->sd = k->sd;
+                desc->xyzsd[4 * q] = k->xd * f;
+                desc->xyzsd[4 * q + 1] = k->yd * f;
+                desc->xyzsd[4 * q + 2] = k->zd * f;
+                desc->xyzsd[4 * q + 3] = k->sd;
+            }
         }
-    for (i = 0; i < n; i++) {
-        const keypoint_t *k = kp->buf + own_idx[i];
-        const double f = ldexp(1.0, k->o);                 /* sift.c:1459, 1530-1533 */
-        desc->xyzsd[4 * (size_t)i] = k->xd * f;
-        desc->xyzsd[4 * (size_t)i + 1] = k->yd * f;
-        desc->xyzsd[4 * (size_t)i + 2] = k->zd * f;
-        desc->xyzsd[4 * (size_t)i + 3] = k->sd;
     }
     {
         float *dev_view = (float *)sift3d_hip_host_device_ptr(desc->hist);
