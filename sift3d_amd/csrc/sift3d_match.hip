@@ -20,7 +20,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int MT = 128, NT = 128, KC = 16;      // block of A rows, of B rows, K chunk
+constexpr int MT = 128, NT = 128, KC = 32;      // block of A rows, of B rows, K chunk
+constexpr int LDK = KC + 4;                      // LDS row stride in floats (see k_nn2)
 
 // squared norms of the rows
 __global__ __launch_bounds__(256) void k_row_norms(const float *__restrict__ a, int n, int dim,
@@ -77,24 +78,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     out_j += (size_t)blockIdx.y * nA;
     out_d1 += (size_t)blockIdx.y * nA;
     out_d2 += (size_t)blockIdx.y * nA;
-    // k-major tiles: As[k][row], so that the lanes of an MFMA operand (row = lane & 31,
-    // k = lane >> 5) read 32 consecutive floats.  Double-buffered: the global loads of chunk
-    // c + 1 are in flight during the MFMAs of chunk c and go to the other buffer afterwards --
-    // one barrier per chunk.
-    // row stride 130: the transposing stores of a wave (lanes 2 r and 2 r + 1 write row r of k rows
-    // sk = 0 and 8) land 8 * 130 = 1040 floats apart = 16 banks apart -- with stride 132 the two lanes of
-    // a pair shared a bank (2-way conflict on every staging store); the operand reads stay 32
-    // consecutive floats
-    __shared__ float As[2][KC][MT + 2];
-    __shared__ float Bs[2][KC][NT + 2];
+    // Row-major tiles As[row][k] (as the rows lie in memory: the staging stores are 16-byte stores of what
+    // the 16-byte global loads delivered, no transposition), rows LDK = KC + 4 floats apart.  A lane of an
+    // MFMA operand (row = lane & 31, half h = lane >> 5) takes FOUR k at a time with one 16-byte read,
+    // k = 8 g + 4 h + {0, 1, 2, 3}: the j-th of the four v_mfma_f32_32x32x2_f32 of group g then multiplies the
+    // k pair (8 g + j, 8 g + 4 + j) -- any pairing will do, a dot product does not care about the order
+    // of its terms, as long as A and B use the same one.  Eight consecutive lanes read rows 36 floats
+    // apart: 4-float slots at 0, 4, ..., 28 modulo the 32 banks -- conflict-free; a chunk needs 16
+    // 16-byte reads and 8 16-byte stores per lane where the k-major layout needed 64 + 32 4-byte ones.
+    // Double-buffered: the global loads of chunk c + 1 are in flight during the 64 MFMAs of chunk c and go
+    // to the other buffer afterwards -- one barrier per chunk of KC = 32 (two tiles of 2 x 18 KB per
+    // workgroup, two workgroups per CU).
+    __shared__ __attribute__((aligned(16))) float As[2][MT][LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][NT][LDK];
     __shared__ float red_d1[MT][2], red_d2[MT][2];
     __shared__ int red_j[MT][2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1;            // 2 x 2 waves, 64 x 64 outputs each
     const int i0 = blockIdx.x * MT;
     const int lr = lane & 31, lh = lane >> 5;
-    // staging role: thread t copies 8 consecutive k of one row
-    const int srow = tid >> 1, sk = (tid & 1) * 8;
+    // staging role: thread t copies the 16-byte pieces (row (t >> 3) + 32 i, columns 4 (t & 7) ..) of both
+    // tiles, i = 0..3: eight consecutive lanes cover the 128 contiguous bytes of a row's chunk
+    const int srow = tid >> 3, sc4 = (tid & 7) * 4;
     const int nk = dim / KC;
 
     Top2 best[2][16];
@@ -105,10 +110,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             best[t][r].d1 = best[t][r].d2 = __builtin_inff();
             best[t][r].j1 = 0x7fffffff;
         }
-    const int ra = i0 + srow;
-    const float *pa = A + (size_t)min(ra, nA - 1) * dim + sk;
-    const bool a_ok = ra < nA;
-
+    // (row addresses are recomputed per load rather than kept in 16 registers: the kernel lives at the edge
+    // of its 256)
+    const uint32_t udim = (uint32_t)dim;
     for (int j0 = jlo; j0 < jhi; j0 += NT) {
         f32x16 acc[2][2];
 #pragma unroll
@@ -118,51 +122,78 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int r = 0; r < 16; r++)
                     acc[a][b][r] = 0.0f;
-        const int rb = j0 + srow;
-        const float *pb = B + (size_t)min(rb, nB - 1) * dim + sk;
-        const bool b_ok = rb < nB;
-        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 va0, va1, vb0, vb1;
-        auto fetch = [&](int c) {
-            va0 = a_ok ? ld4(pa + c * KC) : zero4;
-            va1 = a_ok ? ld4(pa + c * KC + 4) : zero4;
-            vb0 = b_ok ? ld4(pb + c * KC) : zero4;
-            vb1 = b_ok ? ld4(pb + c * KC + 4) : zero4;
-        };
-        auto commit = [&](int buf) {
-            As[buf][sk + 0][srow] = va0.x; As[buf][sk + 1][srow] = va0.y; As[buf][sk + 2][srow] = va0.z; As[buf][sk + 3][srow] = va0.w;
-            As[buf][sk + 4][srow] = va1.x; As[buf][sk + 5][srow] = va1.y; As[buf][sk + 6][srow] = va1.z; As[buf][sk + 7][srow] = va1.w;
-            Bs[buf][sk + 0][srow] = vb0.x; Bs[buf][sk + 1][srow] = vb0.y; Bs[buf][sk + 2][srow] = vb0.z; Bs[buf][sk + 3][srow] = vb0.w;
-            Bs[buf][sk + 4][srow] = vb1.x; Bs[buf][sk + 5][srow] = vb1.y; Bs[buf][sk + 6][srow] = vb1.z; Bs[buf][sk + 7][srow] = vb1.w;
-        };
-        __syncthreads();                    // the previous block's last MFMAs have read buffer (nk - 1) & 1
-        fetch(0);
-        commit(0);
-        __syncthreads();
-        for (int c = 0; c < nk; c++) {
-            const int buf = c & 1;
-            if (c + 1 < nk)
-                fetch(c + 1);               // in flight during the MFMAs below
+        float4 vs[4];                       // staging registers: the A pieces of a chunk, then its B pieces
+        auto fetch = [&](const float *__restrict__ M, int r0, int nrows, int c) {
 #pragma unroll
-            for (int kk = 0; kk < KC; kk += 2) {
-                float fa[2], fb[2];
+            for (int i = 0; i < 4; i++) {
+                const int rr = r0 + srow + 32 * i;
+                // rows beyond the end repeat the last row: their distances are never used (the epilogue skips
+                // columns >= nB, the final store rows >= nA) -- and nothing may depend on the loaded value
+                // here, or the load could not stay in flight during the MFMAs
+                vs[i] = ld4(M + ((size_t)((uint32_t)min(rr, nrows - 1)) * udim + (uint32_t)(sc4 + c * KC)));
+            }
+        };
+        auto commit = [&](float (*T)[LDK]) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                *reinterpret_cast<float4 *>(&T[srow + 32 * i][sc4]) = vs[i];
+        };
+        // eight k of the chunk: two halves of four, each with 8-byte operand reads (16-byte reads would
+        // hold 16 operand registers where 8 do, and the kernel has none to spare)
+        auto group = [&](int buf, int g) {
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                float2 fa[2], fb[2];
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
-                    fa[t] = As[buf][kk + lh][wr * 64 + t * 32 + lr];
-                    fb[t] = Bs[buf][kk + lh][wc * 64 + t * 32 + lr];
+                    fa[t] = *reinterpret_cast<const float2 *>(&As[buf][wr * 64 + t * 32 + lr][8 * g + 4 * lh + 2 * hf]);
+                    fb[t] = *reinterpret_cast<const float2 *>(&Bs[buf][wc * 64 + t * 32 + lr][8 * g + 4 * lh + 2 * hf]);
                 }
 #pragma unroll
-                for (int a = 0; a < 2; a++)
+                for (int j = 0; j < 2; j++) {
+                    const float xa[2] = { j == 0 ? fa[0].x : fa[0].y, j == 0 ? fa[1].x : fa[1].y };
+                    const float xb[2] = { j == 0 ? fb[0].x : fb[0].y, j == 0 ? fb[1].x : fb[1].y };
 #pragma unroll
-                    for (int b = 0; b < 2; b++)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                    for (int a = 0; a < 2; a++)
+#pragma unroll
+                        for (int b = 0; b < 2; b++)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[a], xb[b], acc[a][b], 0, 0, 0);
+                }
             }
-            if (c + 1 < nk)
-                commit(buf ^ 1);            // (its last readers passed the barrier of chunk c - 1)
+        };
+        __syncthreads();                    // the previous block's last MFMAs have read buffer (nk - 1) & 1
+        fetch(A, i0, nA, 0);
+        commit(As[0]);
+        fetch(B, j0, nB, 0);
+        commit(Bs[0]);
+        __syncthreads();
+        static_assert(KC == 32, "four groups of eight k per chunk");
+        for (int c = 0; c < nk; c++) {
+            const int buf = c & 1;
+            const bool more = c + 1 < nk;
+            // the next chunk's pieces travel through ONE set of staging registers: A's are requested before
+            // the first group of MFMAs and stored after the second, B's requested then and stored after the
+            // fourth (the other buffer's last readers passed the barrier of chunk c - 1)
+            if (more)
+                fetch(A, i0, nA, c + 1);
+            group(buf, 0);
+            group(buf, 1);
+            if (more) {
+                commit(As[buf ^ 1]);
+                fetch(B, j0, nB, c + 1);
+            }
+            group(buf, 2);
+            group(buf, 3);
+            if (more)
+                commit(Bs[buf ^ 1]);
             __syncthreads();
         }
         // distances of this block: element r of lane l of tile (a, b) is
-        // (row = 32 a + (r & 3) + 8 (r >> 2) + 4 (l >> 5), col = 32 b + (l & 31))
+        // (row = 32 a + (r & 3) + 8 (r >> 2) + 4 (l >> 5), col = 32 b + (l & 31)).
+        // |a - b|^2 = |a|^2 + (|b|^2 - 2 a.b): for a fixed row the first term is a constant, so the top-2
+        // bookkeeping runs on e = |b|^2 - 2 a.b and k_nn2_merge adds |a|^2 (and clamps at 0) at the very end --
+        // the row norms stay out of this loop (read here, 32 per lane and block, each load was waited for
+        // before the next could be issued: as long as the block's MFMAs).
 #pragma unroll
         for (int b = 0; b < 2; b++) {
             const int col = j0 + wc * 64 + b * 32 + lr;
@@ -171,13 +202,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int a = 0; a < 2; a++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    // |a - b|^2, clamped at 0 (cancellation for near-identical descriptors)
-                    // (|a|^2 is re-read per block instead of living in 32 registers: the kernel
-                    // then fits two waves per SIMD)
-                    const int row = i0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float d = fmaxf(normA[min(row, nA - 1)] + nb - 2.0f * acc[a][b][r], 0.0f);
+                    const float e = nb - 2.0f * acc[a][b][r];
                     if (col < nB)
-                        top2_push(best[a][r], d, col);
+                        top2_push(best[a][r], e, col);
                 }
         }
     }
@@ -213,11 +240,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // Top-2 of a row = merge of its top-2 over the runs of B (lexicographic ties: the result does not
-// depend on how B was cut).
+// depend on how B was cut), then e -> |a - b|^2 = max(|a|^2 + e, 0) (clamped: cancellation for near-identical
+// descriptors).
 __global__ __launch_bounds__(256) void k_nn2_merge(const int *__restrict__ pj, const float *__restrict__ pd1,
                                                    const float *__restrict__ pd2, int nsplit, int nA,
-                                                   int *__restrict__ out_j, float *__restrict__ out_d1,
-                                                   float *__restrict__ out_d2)
+                                                   const float *__restrict__ normA, int *__restrict__ out_j,
+                                                   float *__restrict__ out_d1, float *__restrict__ out_d2)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nA)
@@ -226,9 +254,10 @@ __global__ __launch_bounds__(256) void k_nn2_merge(const int *__restrict__ pj, c
     t.d1 = pd1[i]; t.d2 = pd2[i]; t.j1 = pj[i];
     for (int s = 1; s < nsplit; s++)
         top2_merge(t, pd1[(size_t)s * nA + i], pd2[(size_t)s * nA + i], pj[(size_t)s * nA + i]);
+    const float na = normA[i];
     out_j[i] = t.j1 == 0x7fffffff ? -1 : t.j1;
-    out_d1[i] = t.d1;
-    out_d2[i] = t.d2;
+    out_d1[i] = fmaxf(na + t.d1, 0.0f);
+    out_d2[i] = fmaxf(na + t.d2, 0.0f);
 }
 
 // runs of B per row block of A: enough workgroups to fill the device several times over (a 128-row
@@ -275,7 +304,7 @@ int sift3d_hip_nn2(const float *d_A, int nA, const float *d_B, int nB, int dim, 
         float *pd1 = part + (size_t)ns * nA, *pd2 = part + 2 * (size_t)ns * nA;
         hipLaunchKernelGGL(k_nn2, dim3((nA + MT - 1) / MT, ns), dim3(256), 0, st, d_A, nA, d_B, nB, dim, nrmA,
                            nrmB, per > 0 ? per : 1, pj, pd1, pd2);
-        hipLaunchKernelGGL(k_nn2_merge, dim3((nA + 255) / 256), dim3(256), 0, st, pj, pd1, pd2, ns, nA, d_j1,
+        hipLaunchKernelGGL(k_nn2_merge, dim3((nA + 255) / 256), dim3(256), 0, st, pj, pd1, pd2, ns, nA, nrmA, d_j1,
                            d_d1, d_d2);
     }
     LAUNCH_CHECK();
