@@ -512,7 +512,7 @@ def test_orientation_parallel_sums_equal_serial_sums(gpu, oracle_mod, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["lattice160", "noise96", "spike128", "aniso"])
+@pytest.mark.parametrize("case", ["lattice160", "noise96", "spike128", "aniso", "retry128"])
 def test_dogmax_gathered_by_the_sweep_equals_its_own_pass(gpu, oracle_mod, case):
     """Octave 0's dogmax scan (sift.c:821-826) has no pass of its own by default: the extrema sweep is
     thresholded with LOWER bounds from a sub-lattice, gathers the exact maxima and the reference's threshold
@@ -527,7 +527,12 @@ def test_dogmax_gathered_by_the_sweep_equals_its_own_pass(gpu, oracle_mod, case)
         vol = np.random.default_rng(3).standard_normal((96, 96, 96)).astype(np.float32)
     elif case == "spike128":
         vol = np.random.default_rng(4).random((128, 128, 128), dtype=np.float32)
-        vol[65, 33, 77] = 400.0            # (z, y, x): z % 3 != 1, y odd
+        vol[68, 34, 77] = 400.0            # (z, y, x): two planes and a row off the sub-lattice z = 1 (mod 5), y = 0 (mod 3)
+    elif case == "retry128":
+        # more candidates than the first candidate buffer holds: the sweep runs twice (the maxima it gathers
+        # must come out the same)
+        vol = np.random.default_rng(5).random((128, 128, 128), dtype=np.float32)
+        kw = dict(peak_thresh=0.001, corner_thresh=0.9)
     else:
         vol, units = oracle_mod.synth_survey((72, 60, 80)), (1.0, 1.5, 0.7)
     got = {}
