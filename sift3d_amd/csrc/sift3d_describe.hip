@@ -13,12 +13,15 @@
 // ---------------------------------------------------------------------------------------
 // extract_descrip  (sift.c:1442-1536): one wave per keypoint.
 //
-// Scan    (64 voxels in parallel): exact window test, survivors stream-compacted into an LDS
+// Scan    (64 voxels in parallel): window test (a cheap evaluation with margins, the reference's
+//         expressions where a lane is in doubt), survivors stream-compacted into an LDS
 //         queue so that the expensive phases always run on 64 window voxels.
 // Phase A (one lane per voxel): gradient, Gaussian weight, rotation into keypoint space,
 //         icosahedron face + barycentrics, the eight trilinear cell weights -- the reference's
 //         float expressions, so every per-voxel DECISION (window, |g| threshold, face, skipped
-//         corner) and every per-voxel VALUE is the reference's bit for bit.
+//         corner) is the reference's, and every per-voxel VALUE bit for bit but two: the gradient
+//         magnitude (v_sqrt_f32, 1 ulp) and the product mag * w_cell * bary, which the commit's
+//         fused multiply-add does not round on its own (DESC_OPT below).
 // Phase B (commit): a voxel adds mag*w_cell*bary_j to 24 distinct bins (8 cells x 3 face
 //         vertices), which 24 lanes do as ONE plain LDS read-modify-write.  The two half-waves
 //         commit two voxels per round into two PRIVATE histograms, which are added at the end.
