@@ -1761,7 +1761,7 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
 {
     const int num = (int)kp->num;
     const double t_start = now_s();
-    int i;
+    int i, lvbad = 0;
 
     /* verify_keys, sift.c:1171-1212 (against the retained image dimensions) */
     if (num < 1) {
@@ -1771,12 +1771,13 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
     {
         /* the checks on a few threads; the first offender (if any) is then reported in list order */
         int bad = 0;
-#pragma omp parallel for num_threads(host_threads((size_t)num)) schedule(static) reduction(| : bad)
+#pragma omp parallel for num_threads(host_threads((size_t)num)) schedule(static) reduction(| : bad, lvbad)
         for (i = 0; i < num; i++) {
             const keypoint_t *k = kp->buf + i;
             const double f = k->o >= 0 && k->o < 64 ? (double)(1ull << k->o) : ldexp(1.0, k->o);
             bad |= k->xd < 0 || k->yd < 0 || k->zd < 0 || k->xd * f >= (double)d->nx ||
                    k->yd * f >= (double)d->ny || k->zd * f >= (double)d->nz || k->sd <= 0;
+            lvbad |= k->o < 0 || k->o >= d->num_octaves || k->s < -1 || k->s > d->ngl - 2;
         }
         for (i = 0; i < num && bad; i++) {
             const keypoint_t *k = kp->buf + i;
@@ -1801,7 +1802,7 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
             "SIFT3D_detect_keypoints was called prior to calling this function. \n");
         return SIFT3D_FAILURE;
     }
-    for (i = 0; i < num; i++) {
+    for (i = 0; i < num && lvbad; i++) {
         const keypoint_t *k = kp->buf + i;
         if (k->o < 0 || k->o >= d->num_octaves || k->s < -1 || k->s > d->ngl - 2) {
             ERR("sift3d_amd: keypoint %d refers to pyramid level (%d, %d) which does not exist \n",
@@ -1896,8 +1897,8 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
         desc->d_cap = desc->cap;
     }
     sift3d_hip_event_record(d->ev[6], d->stream);
-    if (sift3d_hip_memcpy_h2d(d->d_kp, d->h_kp, sizeof(sift3d_hip_kp) * (size_t)num, d->stream))
-        return SIFT3D_FAILURE;
+    /* (the kernel reads the 64-byte record of a keypoint once, as its wave starts: straight from the
+     * page-locked host list -- no copy, no DMA set-up between the host loops and the launch) */
     /* The kernel stores each histogram straight into the store's page-locked array (mapped
      * into the device's address space): the 3 KB per keypoint trickle over PCIe while the other
      * keypoints are still being computed, so there is no device staging buffer and no D2H
@@ -1905,7 +1906,9 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
      * pays the kernel's long tail.) */
     {
         float *dev_view = (float *)sift3d_hip_host_device_ptr(desc->hist);
-        if (!dev_view || sift3d_hip_describe_wlut2(d->d_levels, d->num_octaves * d->ngl, d->d_kp,
+        const sift3d_hip_kp *kp_view = (const sift3d_hip_kp *)sift3d_hip_host_device_ptr(d->h_kp);
+        if (!dev_view || !kp_view ||
+            sift3d_hip_describe_wlut2(d->d_levels, d->num_octaves * d->ngl, kp_view,
                                                    (uint32_t)num, dev_view,
                                                    desc->keep_device ? desc->d_hist : NULL, d->d_wlut,
                                                    d->stream))

@@ -512,7 +512,7 @@ def test_orientation_parallel_sums_equal_serial_sums(gpu, oracle_mod, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["lattice160", "noise96", "spike128", "aniso", "retry128"])
+@pytest.mark.parametrize("case", ["lattice160", "noise96", "spike128", "aniso", "retry128", "odd256x93x95"])
 def test_dogmax_gathered_by_the_sweep_equals_its_own_pass(gpu, oracle_mod, case):
     """Octave 0's dogmax scan (sift.c:821-826) has no pass of its own by default: the extrema sweep is
     thresholded with LOWER bounds from a sub-lattice, gathers the exact maxima and the reference's threshold
@@ -528,6 +528,9 @@ def test_dogmax_gathered_by_the_sweep_equals_its_own_pass(gpu, oracle_mod, case)
     elif case == "spike128":
         vol = np.random.default_rng(4).random((128, 128, 128), dtype=np.float32)
         vol[68, 34, 77] = 400.0            # (z, y, x): two planes and a row off the sub-lattice z = 1 (mod 5), y = 0 (mod 3)
+    elif case == "odd256x93x95":
+        # rows and planes that are no multiples of the sub-lattice's strides (3 and 5), an odd row count
+        vol = np.random.default_rng(6).standard_normal((95, 93, 256)).astype(np.float32)
     elif case == "retry128":
         # more candidates than the first candidate buffer holds: the sweep runs twice (the maxima it gathers
         # must come out the same)
