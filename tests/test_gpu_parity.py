@@ -406,6 +406,28 @@ def test_reuse_and_errors(gpu, oracle_mod):
     np.testing.assert_array_equal(kp.to_mat_rm(), o.kp_mat())
 
 
+def test_descriptors_across_reuse(gpu, oracle_mod):
+    """One detector and one pair of stores on alternating volumes: the describe kernel reads the keypoint
+    records from the page-locked host list and writes the histograms into the store's page-locked array --
+    every call must see THIS call's records (bitwise equal to a fresh detector's result)."""
+    api, hip, torch = gpu
+    vols = [oracle_mod.synth_lattice(96, seed=s) for s in (3, 4)]
+    fresh = []
+    for v in vols:
+        det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+        assert det.detect_keypoints(api.Image.from_array(v), kp) == 0
+        assert det.extract_descriptors(kp, desc) == 0
+        fresh.append((kp.to_mat_rm().copy(), desc.to_mat_rm().copy()))
+    assert len(fresh[0][1]) > 0 and len(fresh[1][1]) > 0 and fresh[0][1].shape != fresh[1][1].shape or \
+        not np.array_equal(fresh[0][1], fresh[1][1])
+    det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+    for which in (0, 1, 0, 0, 1):
+        assert det.detect_keypoints(api.Image.from_array(vols[which]), kp) == 0
+        assert det.extract_descriptors(kp, desc) == 0
+        np.testing.assert_array_equal(kp.to_mat_rm(), fresh[which][0])
+        np.testing.assert_array_equal(desc.to_mat_rm(), fresh[which][1])
+
+
 def test_g5_512_golden(gpu, oracle_mod):
     """BASELINE configs[2] -- the bench workload (512^3 lattice volume, seed 11) -- against the
     reference's own results (sha1 digests + strided samples, tests/golden/g5_512.npz)."""
