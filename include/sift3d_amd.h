@@ -307,6 +307,12 @@ typedef struct {
 
 SIFT3D_AMD_API int
 sift3d_hip_fir(const sift3d_hip_fir_args *args, void *stream);
+/* The x pass of a unit-spaced blur applied to src / *d_max: im_scale (imutil.c:698-713; *d_max = max|src|
+ * from sift3d_hip_absmax, 0: no scaling) folded into the first pass of the pyramid, so that the scaled image
+ * is never stored.  Same result as sift3d_hip_scale followed by sift3d_hip_fir.  1: not covered (axis other
+ * than x, tap spacing other than 1, more than 17 taps, the literal variant). */
+SIFT3D_AMD_API int
+sift3d_hip_fir_x_scaled(const sift3d_hip_fir_args *args, const float *d_max, void *stream);
 
 /* The y and z passes of one blur fused into one launch when both have tap spacing 1 (octave 0):
  * dst = FIR_z(FIR_y(src)), bit-identical to two sift3d_hip_fir calls, without the intermediate

@@ -131,6 +131,8 @@ struct _sift3d_detector {
     unsigned char dog_free[64]; /* per octave: the last detect formed its DoG levels on the fly */
     float *d_scalars;      /* [0] input max, [1] count (as u32), [8 + o*ndl + s] dogmax, then
                             * [8 + (num_octaves + o)*ndl + s] their lower bounds (sift3d_hip_dogmax_sub) */
+    int im_valid;          /* d_im holds the scaled image of the last detect call (else: see last_vol) */
+    const float *last_vol; /* the last detect call's volume on the device (the caller's, or d_in) */
     int est0;              /* the large octaves' maxima gathered by their extrema sweeps (default; 0: a pass
                             * of their own) */
     sift3d_hip_level *h_levels, *d_levels;
@@ -1266,9 +1268,12 @@ static int ensure_dog_octave(sift3d_detector *d, int o)
 
 /* apply_Sep_FIR_filter (imutil.c:1127-1206) on the device: x, y, z passes, the two
  * intermediates in scratch volumes, no permute copies */
+/* d_scale_max (first blur of the pyramid only, else NULL): the blur of src / *d_scale_max -- im_scale folded
+ * into the x pass; returns 2 without doing anything when the configuration's x pass cannot do that (the
+ * caller then scales the image first) */
 static int blur_level(sift3d_detector *d, const float *src, float *dst, const int *dims,
                       const double *lu, const filter_t *f, void *stream, float *tmp_a, float *tmp_b,
-                      int time_yz)
+                      int time_yz, const float *d_scale_max)
 {
     const float *in = src;
     float *outs[3];
@@ -1287,7 +1292,13 @@ static int blur_level(sift3d_detector *d, const float *src, float *dst, const in
         a.axis = 0; a.width = f->width; a.taps = f->taps;
         a.unit_factor = (float)(1.0 / lu[0]);
         a.n_glob = dims[2]; a.z_lo = 0; a.z_hi = dims[2];
-        if (sift3d_hip_fir(&a, stream))
+        if (d_scale_max) {
+            rc = sift3d_hip_fir_x_scaled(&a, d_scale_max, stream);
+            if (rc == 1)
+                return 2;
+            if (rc != SIFT3D_SUCCESS)
+                return SIFT3D_FAILURE;
+        } else if (sift3d_hip_fir(&a, stream))
             return SIFT3D_FAILURE;
         if (time_yz)
             sift3d_hip_event_record(d->ev_yz[0], stream);
@@ -1316,6 +1327,8 @@ static int blur_level(sift3d_detector *d, const float *src, float *dst, const in
         }
         return SIFT3D_SUCCESS;
     }
+    if (d_scale_max)
+        return 2;
     for (ax = 0; ax < 3; ax++) {
         sift3d_hip_fir_args a;
         memset(&a, 0, sizeof(a));
@@ -1389,19 +1402,32 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     sift3d_hip_event_record(d->ev[0], d->stream);
     if (sift3d_hip_memset(d->d_scalars, 0, sizeof(float) * (8 + 2 * (size_t)d->num_octaves * d->ndl),
                           d->stream) ||
-        sift3d_hip_absmax(d_vol, n0, d->d_scalars, d->stream) ||
-        sift3d_hip_scale(d_vol, d->d_im, n0, d->d_scalars, d->stream))
+        sift3d_hip_absmax(d_vol, n0, d->d_scalars, d->stream))
         return SIFT3D_FAILURE;
 
-    /* build_gpyr, sift.c:662-711 */
+    /* build_gpyr, sift.c:662-711.  The first blur reads the volume itself and divides every sample by the
+     * maximum as it stages it (im_scale, imutil.c:698-713): the scaled image -- read by nothing else -- is
+     * not stored (8 B/voxel less; sift3d_amd_copy_level forms it on demand from `last_vol`).  Where the x
+     * pass cannot do that (other tap spacings) the image is scaled first, as before. */
     d->yz_timed = 0;
     sift3d_hip_event_record(d->ev[1], d->stream);
     {
         double lu[3];
+        int rc;
         level_units(d, 0, lu);
-        if (blur_level(d, d->d_im, d->d_g[0], d->odims[0], lu, &d->filt[0], d->stream, d->d_tmp_a,
-                       d->d_tmp_b, 0))
+        rc = blur_level(d, d_vol, d->d_g[0], d->odims[0], lu, &d->filt[0], d->stream, d->d_tmp_a,
+                        d->d_tmp_b, 0, d->d_scalars);
+        d->im_valid = 0;
+        d->last_vol = d_vol;
+        if (rc == 2) {
+            if (sift3d_hip_scale(d_vol, d->d_im, n0, d->d_scalars, d->stream) ||
+                blur_level(d, d->d_im, d->d_g[0], d->odims[0], lu, &d->filt[0], d->stream, d->d_tmp_a,
+                           d->d_tmp_b, 0, NULL))
+                return SIFT3D_FAILURE;
+            d->im_valid = 1;
+        } else if (rc != SIFT3D_SUCCESS) {
             return SIFT3D_FAILURE;
+        }
     }
     {
         /* Octave o + 1 starts from level max(s_end - 2, first_level) of octave o (sift.c:696-704);
@@ -1422,7 +1448,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                 /* octave 0 up to the source level, then the fork */
                 for (s = 1; s <= ds + 1; s++)
                     if (blur_level(d, d->d_g[s - 1], d->d_g[s], d->odims[0], lu, &d->filt[s], d->stream,
-                                   d->d_tmp_a, d->d_tmp_b, 0))
+                                   d->d_tmp_a, d->d_tmp_b, 0, NULL))
                         return SIFT3D_FAILURE;
                 if (sift3d_hip_event_record(d->ev_fork, d->stream) ||
                     sift3d_hip_stream_wait_event(d->oct_stream, d->ev_fork))
@@ -1433,7 +1459,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                     return SIFT3D_FAILURE;
                 for (; s < d->ngl; s++)
                     if (blur_level(d, d->d_g[s - 1], d->d_g[s], d->odims[0], lu, &d->filt[s], d->stream,
-                                   d->d_tmp_a, d->d_tmp_b, s == d->ngl - 1))
+                                   d->d_tmp_a, d->d_tmp_b, s == d->ngl - 1, NULL))
                         return SIFT3D_FAILURE;
                 continue;
             }
@@ -1453,7 +1479,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                     tb = d->d_tmp3_b;
                 }
                 if (blur_level(d, d->d_g[o * d->ngl + s - 1], d->d_g[o * d->ngl + s], d->odims[o], lu,
-                               &d->filt[s], st, ta, tb, o == 0 && s == d->ngl - 1)) /* gauss_octave[s], sift.c:689 */
+                               &d->filt[s], st, ta, tb, o == 0 && s == d->ngl - 1, NULL)) /* gauss_octave[s], sift.c:689 */
                     return SIFT3D_FAILURE;
             }
             if (o != d->num_octaves - 1 && !forked) {
@@ -1940,6 +1966,14 @@ int sift3d_amd_copy_level(const sift3d_detector *d, int which, int o, int s, flo
         return SIFT3D_FAILURE;
     if (which == 2) {
         o = 0;
+        if (!d->im_valid) {
+            /* the scaled image was folded into the first blur: form it now (im_scale) from the last
+             * volume -- for sift3d_amd_detect_keypoints_device that is the CALLER's buffer, which must
+             * still hold the volume */
+            const size_t n0 = (size_t)d->odims[0][0] * d->odims[0][1] * d->odims[0][2];
+            if (!d->last_vol || sift3d_hip_scale(d->last_vol, d->d_im, n0, d->d_scalars, d->stream))
+                return SIFT3D_FAILURE;
+        }
         src = d->d_im;
     } else {
         const int nl = which == 0 ? d->ngl : d->ndl;

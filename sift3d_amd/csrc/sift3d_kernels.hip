@@ -464,8 +464,13 @@ __global__ __launch_bounds__(256) void k_fir_x_u1(FirParams P, FirTaps T, EdgeTa
     const int epos = egi - (x0 - HALO);
     const bool has_edge = lane < 17 && epos >= 0 && epos < L;
 
+    // im_scale folded in (P.scale_max): the quotient v / max of imutil.c:711 is formed when a row is committed
+    // to LDS -- not when it is requested: nothing may depend on a load in flight -- and the edge samples
+    // are built from scaled samples, as the reference builds them from the scaled image
+    const float smax = P.scale_max ? *P.scale_max : 0.0f;
+    const bool scaled = smax != 0.0f;                          // (max == 0: im_scale leaves the image alone)
     float4 v[NV];
-    float ve = 0.0f;
+    float ve = 0.0f, ve2 = 0.0f, ew0 = 1.0f, ew1 = 0.0f;
     auto fetch = [&](int r) {
         const float *__restrict__ s = P.src + base + (size_t)(row0 + r) * nx;
 #pragma unroll
@@ -483,20 +488,42 @@ __global__ __launch_bounds__(256) void k_fir_x_u1(FirParams P, FirTaps T, EdgeTa
                 }
             }
         }
-        // edge samples of the extended line, one per lane: E[-1..-8] and E[end..end+8]
-        if (has_edge)
-            ve = ext_sample(s, 1, egi, end, 0, nx, HW, E);
+        // edge samples of the extended line, one per lane: E[-1..-8] and E[end..end+8] (the two samples and
+        // weights of ext_sample's cases; combined in commit)
+        if (has_edge) {
+            ve = ve2 = 0.0f;
+            ew0 = 1.0f;
+            ew1 = 0.0f;
+            if (egi < 0) {
+                if (-egi <= HW)
+                    ve = s[clampi(-egi, 0, nx - 1)];
+            } else if (egi - end <= HW) {
+                const int m = egi - end, lo = E.lo[m];
+                ve = s[clampi(lo, 0, nx - 1)];
+                ve2 = s[clampi(lo + 1, 0, nx - 1)];
+                ew0 = E.w0[m];
+                ew1 = E.w1[m];
+            }
+        }
     };
     auto commit = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             const int i = lane + 64 * k;
-            if (i < L / 4)
-                *reinterpret_cast<float4 *>(&lds[wave][buf][4 * i]) = v[k];
+            if (i < L / 4) {
+                float4 q = v[k];
+                if (scaled) {
+                    q.x = q.x / smax; q.y = q.y / smax; q.z = q.z / smax; q.w = q.w / smax;   // imutil.c:711
+                }
+                *reinterpret_cast<float4 *>(&lds[wave][buf][4 * i]) = q;
+            }
         }
         // DS writes of a wave retire in order: the edge samples overwrite the bulk values
-        if (has_edge)
-            lds[wave][buf][epos] = ve;
+        if (has_edge) {
+            const float a = scaled ? ve / smax : ve, b = scaled ? ve2 / smax : ve2;
+            // (ext_sample's cases: a lone sample is 1 * a + 0 * b = a exactly; beyond the taps' reach 0)
+            lds[wave][buf][epos] = egi >= end ? ew0 * a + ew1 * b : a;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
     };
@@ -2751,7 +2778,24 @@ int sift3d_hip_scale(const float *d_src, float *d_dst, size_t n, const float *d_
     return SIFT3D_SUCCESS;
 }
 
-int sift3d_hip_fir(const sift3d_hip_fir_args *a, void *stream)
+static int fir_impl(const sift3d_hip_fir_args *a, const float *d_scale_max, void *stream);
+
+int sift3d_hip_fir(const sift3d_hip_fir_args *a, void *stream) { return fir_impl(a, nullptr, stream); }
+
+// The x pass of a unit-spaced blur on src / *d_max (im_scale, imutil.c:698-713, folded into the pass: the
+// scaled image is never stored).  1: not covered (the caller scales first, then calls sift3d_hip_fir).
+int sift3d_hip_fir_x_scaled(const sift3d_hip_fir_args *a, const float *d_max, void *stream)
+{
+    if (!a || !d_max)
+        return SIFT3D_FAILURE;
+    const int hw = a->width / 2;
+    if (a->axis != 0 || a->variant == 1 || a->unit_factor != 1.0f || hw < 1 || hw > 8 || a->nx < 2 * hw + 2 ||
+        a->nx >= (1 << 22))
+        return 1;
+    return fir_impl(a, d_max, stream);
+}
+
+static int fir_impl(const sift3d_hip_fir_args *a, const float *d_scale_max, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!a || !a->src || !a->dst || a->nx < 1 || a->ny < 1 || a->nz < 1 || a->axis < 0 ||
@@ -2778,6 +2822,7 @@ int sift3d_hip_fir(const sift3d_hip_fir_args *a, void *stream)
     P.off = a->axis == 2 ? a->off : 0;
     P.z_lo = a->z_lo; P.z_hi = a->z_hi;
     P.ts = 64;
+    P.scale_max = d_scale_max;
     if (a->axis == 2 && (P.off < 0 || P.off + a->nz > P.n_glob)) {
         snprintf(g_err, sizeof(g_err), "sift3d_hip_fir: slab outside the global axis");
         fprintf(stderr, "sift3d_amd: %s\n", g_err);

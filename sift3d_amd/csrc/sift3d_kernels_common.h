@@ -49,6 +49,8 @@ struct FirParams {
     int n_glob, off;  // along the filtered axis
     int z_lo, z_hi;   // output planes
     int ts;           // sweep segment length (sweep kernels)
+    const float *scale_max;   // k_fir_x_u1 only: every sample is divided by *scale_max first (im_scale,
+                              // imutil.c:698-713, folded into the first pass of the pyramid); or null
 };
 
 // High-edge samples of the extended line of a unit-spaced pass (see "unit factor 1" in
