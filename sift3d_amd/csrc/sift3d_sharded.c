@@ -439,8 +439,11 @@ static int sh_fir(sift3d_amd_sharded *S, const float *src, float *dst, int o, in
 /* apply_Sep_FIR_filter (imutil.c:1127-1206) on a level: src -> dst (same geometry).  Sharded
  * octaves: x (and y) on the owned planes, halo exchange of the z pass's input overlapped with the
  * z pass of the interior planes. */
+/* d_scale_max (the first blur of the pyramid only, else NULL): the blur of src / *d_scale_max -- im_scale
+ * folded into the x pass (sift3d_hip_fir_x_scaled); returns 2 without doing anything when that x pass does
+ * not cover the configuration */
 static int sh_blur(sift3d_amd_sharded *S, int o, const float *src, const sh_level *Lg, float *dst,
-                   const filter_t *f)
+                   const filter_t *f, const float *d_scale_max)
 {
     const size_t plane = sh_plane(S, o);
     const int nx = S->dims[o][0], ny = S->dims[o][1], nzo = S->dims[o][2];
@@ -454,7 +457,21 @@ static int sh_blur(sift3d_amd_sharded *S, int o, const float *src, const sh_leve
     const int exch = S->world > 1 && sh_sharded(S, o);
     float *zin;
     int fused, ia, ib, rc;
-    if (sh_fir(S, src, S->d_tmp_a, o, Lg->nloc, 0, f, ufx, 0, a, b, S->stream))
+    if (d_scale_max) {
+        sift3d_hip_fir_args fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.src = src; fa.dst = S->d_tmp_a;
+        fa.nx = nx; fa.ny = ny; fa.nz = Lg->nloc;
+        fa.axis = 0; fa.width = f->width; fa.taps = f->taps;
+        fa.unit_factor = ufx;
+        fa.n_glob = nzo; fa.off = 0;
+        fa.z_lo = a; fa.z_hi = b;
+        rc = sift3d_hip_fir_x_scaled(&fa, d_scale_max, S->stream);
+        if (rc == 1)
+            return 2;
+        if (rc != SIFT3D_SUCCESS)
+            return SIFT3D_FAILURE;
+    } else if (sh_fir(S, src, S->d_tmp_a, o, Lg->nloc, 0, f, ufx, 0, a, b, S->stream))
         return SIFT3D_FAILURE;
     fused = ufy == 1.0f && ufz == 1.0f && sift3d_hip_fir_yz_u1_covers(S->d_tmp_a, dst, nx, ny, f->width, nzo);
     zin = S->d_tmp_a;
@@ -572,16 +589,29 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
             return SIFT3D_FAILURE;
         if (S->world > 1 && S->T.allreduce_max(S->T.ctx, S->d_scalars, 1, S->stream))
             return SIFT3D_FAILURE;
-        if (sift3d_hip_scale(S->d_raw, S->d_im + (size_t)a * sh_plane(S, 0), n_in, S->d_scalars, S->stream))
-            return SIFT3D_FAILURE;
+        (void)a;        /* (im_scale itself: folded into the first blur below, or run there) */
     }
     /* build_gpyr, sift.c:662-711 */
     sift3d_hip_event_record(S->ev0, S->stream);
     for (o = 0; o < S->num_octaves; o++) {
-        if (o == 0 && sh_blur(S, 0, S->d_im, &S->G[0][0], S->G[0][0].t, &S->filt[0]))
-            return SIFT3D_FAILURE;
+        if (o == 0) {
+            /* the first blur reads the raw slab and scales as it stages (im_scale folded into the x pass:
+             * the scaled image is not stored); where that x pass does not apply, scale first */
+            const sh_level *L0 = &S->G[0][0];
+            const int a0 = sh_sharded(S, 0) ? L0->z0 - L0->off : 0;
+            const size_t n_in = sh_plane(S, 0) * (size_t)(S->in_z1 - S->in_z0);
+            /* (d_raw holds the owned planes only: plane index a0 of the level buffer is its plane 0) */
+            int rc = sh_blur(S, 0, S->d_raw - (size_t)a0 * sh_plane(S, 0), L0, L0->t, &S->filt[0], S->d_scalars);
+            if (rc == 2) {
+                if (sift3d_hip_scale(S->d_raw, S->d_im + (size_t)a0 * sh_plane(S, 0), n_in, S->d_scalars, S->stream) ||
+                    sh_blur(S, 0, S->d_im, L0, L0->t, &S->filt[0], NULL))
+                    return SIFT3D_FAILURE;
+            } else if (rc != SIFT3D_SUCCESS) {
+                return SIFT3D_FAILURE;
+            }
+        }
         for (s = 1; s < S->ngl; s++)
-            if (sh_blur(S, o, S->G[o][s - 1].t, &S->G[o][s], S->G[o][s].t, &S->filt[s]))
+            if (sh_blur(S, o, S->G[o][s - 1].t, &S->G[o][s], S->G[o][s].t, &S->filt[s], NULL))
                 return SIFT3D_FAILURE;
         if (o != S->num_octaves - 1) {
             /* level max(s_end - 2, first_level) = Gaussian index K, sift.c:696-704 */
