@@ -73,6 +73,17 @@ struct sift3d_amd_sharded {
     /* device state */
     void *stream, *comm_stream, *ev_x, *ev_halo, *ev0, *ev1, *ev2, *ev3, *ev4;
     void *oct_stream, *ev_fork, *ev_join;   /* extrema sweeps of octaves >= 1 beside octave 0's */
+    /* The pyramid's three dependency chains, as in the single-GPU path (detect_on_device): [0] octave 0,
+     * [1] the first levels of the octaves >= 1 (their down-sampling source included), [2] their last
+     * levels, which nothing but their own DoG waits for.  A chain has its stream, its scratch volumes and
+     * its pair of events around the z-halo exchange (which always travels on comm_stream). */
+    struct sh_chain {
+        void *stream;
+        float *tmp_a, *tmp_b;
+        void *ev_x, *ev_halo;
+    } chain[3];
+    void *side_stream, *ev_oct[SH_MAX_OCT], *ev_join2, *ev_tr;
+    float *d_tmp2_a, *d_tmp2_b, *d_tmp3_a, *d_tmp3_b;
     void *d_work2;                          /* their work areas, kept until the ordered emission */
     size_t work2_off[SH_MAX_OCT], work2_sz[SH_MAX_OCT], work2_bytes;
     sh_level G[SH_MAX_OCT][SH_MAX_NGL];
@@ -171,6 +182,8 @@ void sift3d_amd_sharded_free(sift3d_amd_sharded *S)
         sift3d_hip_stream_sync(S->comm_stream);
     if (S->oct_stream)
         sift3d_hip_stream_sync(S->oct_stream);
+    if (S->side_stream)
+        sift3d_hip_stream_sync(S->side_stream);
     for (o = 0; o < SH_MAX_OCT; o++) {
         for (s = 0; s < SH_MAX_NGL; s++)
             sh_free_level(&S->G[o][s]);
@@ -180,6 +193,8 @@ void sift3d_amd_sharded_free(sift3d_amd_sharded *S)
     for (s = 0; s < SH_MAX_NGL; s++)
         free(S->filt[s].taps);
     sift3d_hip_free(S->d_tmp_a); sift3d_hip_free(S->d_tmp_b); sift3d_hip_free(S->d_im);
+    sift3d_hip_free(S->d_tmp2_a); sift3d_hip_free(S->d_tmp2_b); sift3d_hip_free(S->d_tmp3_a);
+    sift3d_hip_free(S->d_tmp3_b);
     sift3d_hip_free(S->d_raw); sift3d_hip_free(S->d_stage); sift3d_hip_free(S->d_scalars);
     sift3d_hip_free(S->d_levels); sift3d_hip_free(S->d_work); sift3d_hip_free(S->d_work2);
     sift3d_hip_free(S->d_cand);
@@ -191,6 +206,15 @@ void sift3d_amd_sharded_free(sift3d_amd_sharded *S)
     sift3d_hip_event_destroy(S->ev0); sift3d_hip_event_destroy(S->ev1);
     sift3d_hip_event_destroy(S->ev2); sift3d_hip_event_destroy(S->ev3); sift3d_hip_event_destroy(S->ev4);
     sift3d_hip_event_destroy(S->ev_fork); sift3d_hip_event_destroy(S->ev_join);
+    sift3d_hip_event_destroy(S->ev_join2); sift3d_hip_event_destroy(S->ev_tr);
+    sift3d_hip_event_destroy(S->chain[1].ev_x); sift3d_hip_event_destroy(S->chain[1].ev_halo);
+    sift3d_hip_event_destroy(S->chain[2].ev_x); sift3d_hip_event_destroy(S->chain[2].ev_halo);
+    {
+        int oo;
+        for (oo = 0; oo < SH_MAX_OCT; oo++)
+            sift3d_hip_event_destroy(S->ev_oct[oo]);
+    }
+    sift3d_hip_stream_destroy(S->side_stream);
     sift3d_hip_stream_destroy(S->oct_stream);
     sift3d_hip_stream_destroy(S->comm_stream);
     sift3d_hip_stream_destroy(S->stream);
@@ -274,8 +298,15 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
         !(S->ev2 = sift3d_hip_event_create()) || !(S->ev3 = sift3d_hip_event_create()) ||
         !(S->ev4 = sift3d_hip_event_create()) ||
         !(S->oct_stream = sift3d_hip_stream_create_high()) || !(S->ev_fork = sift3d_hip_event_create()) ||
-        !(S->ev_join = sift3d_hip_event_create()) || upload_mesh())
+        !(S->ev_join = sift3d_hip_event_create()) || !(S->side_stream = sift3d_hip_stream_create_high()) ||
+        !(S->ev_join2 = sift3d_hip_event_create()) || !(S->ev_tr = sift3d_hip_event_create()) ||
+        !(S->chain[1].ev_x = sift3d_hip_event_create()) || !(S->chain[1].ev_halo = sift3d_hip_event_create()) ||
+        !(S->chain[2].ev_x = sift3d_hip_event_create()) || !(S->chain[2].ev_halo = sift3d_hip_event_create()) ||
+        upload_mesh())
         goto fail;
+    for (o = 0; o < S->num_octaves; o++)
+        if (!(S->ev_oct[o] = sift3d_hip_event_create()))
+            goto fail;
     /* levels */
     for (o = 0; o < S->num_octaves; o++) {
         const int nzo = S->dims[o][2];
@@ -310,6 +341,15 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
     S->d_tmp_a = (float *)sift3d_hip_malloc(n0 * sizeof(float));
     S->d_tmp_b = (float *)sift3d_hip_malloc(n0 * sizeof(float));
     S->d_im = (float *)sift3d_hip_malloc(n0 * sizeof(float));
+    {
+        const size_t n1 = S->num_octaves > 1 ? sh_plane(S, 1) * (size_t)S->G[1][0].nloc : 4;
+        S->d_tmp2_a = (float *)sift3d_hip_malloc(n1 * sizeof(float));
+        S->d_tmp2_b = (float *)sift3d_hip_malloc(n1 * sizeof(float));
+        S->d_tmp3_a = (float *)sift3d_hip_malloc(n1 * sizeof(float));
+        S->d_tmp3_b = (float *)sift3d_hip_malloc(n1 * sizeof(float));
+        if (!S->d_tmp2_a || !S->d_tmp2_b || !S->d_tmp3_a || !S->d_tmp3_b)
+            goto fail;
+    }
     S->d_raw = (float *)sift3d_hip_malloc(sh_plane(S, 0) * (size_t)(S->in_z1 - S->in_z0) * sizeof(float));
     /* staging of the sharded -> replicated transition: this rank's down-sampled slab, then the
      * world slabs gathered (all padded to the largest) */
@@ -341,6 +381,10 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
     if (!S->d_wlut || !S->d_tmp_a || !S->d_tmp_b || !S->d_im || !S->d_raw || !S->d_stage || !S->d_scalars ||
         !S->d_levels || !S->d_work)
         goto fail;
+    S->chain[0].stream = S->stream;      S->chain[0].tmp_a = S->d_tmp_a;  S->chain[0].tmp_b = S->d_tmp_b;
+    S->chain[0].ev_x = S->ev_x;          S->chain[0].ev_halo = S->ev_halo;
+    S->chain[1].stream = S->oct_stream;  S->chain[1].tmp_a = S->d_tmp2_a; S->chain[1].tmp_b = S->d_tmp2_b;
+    S->chain[2].stream = S->side_stream; S->chain[2].tmp_a = S->d_tmp3_a; S->chain[2].tmp_b = S->d_tmp3_b;
     /* level table (window kernels) */
     for (o = 0; o < S->num_octaves; o++)
         for (s = 0; s < S->ngl; s++) {
@@ -442,8 +486,8 @@ static int sh_fir(sift3d_amd_sharded *S, const float *src, float *dst, int o, in
 /* d_scale_max (the first blur of the pyramid only, else NULL): the blur of src / *d_scale_max -- im_scale
  * folded into the x pass (sift3d_hip_fir_x_scaled); returns 2 without doing anything when that x pass does
  * not cover the configuration */
-static int sh_blur(sift3d_amd_sharded *S, int o, const float *src, const sh_level *Lg, float *dst,
-                   const filter_t *f, const float *d_scale_max)
+static int sh_blur(sift3d_amd_sharded *S, const struct sh_chain *C, int o, const float *src, const sh_level *Lg,
+                   float *dst, const filter_t *f, const float *d_scale_max)
 {
     const size_t plane = sh_plane(S, o);
     const int nx = S->dims[o][0], ny = S->dims[o][1], nzo = S->dims[o][2];
@@ -460,25 +504,25 @@ static int sh_blur(sift3d_amd_sharded *S, int o, const float *src, const sh_leve
     if (d_scale_max) {
         sift3d_hip_fir_args fa;
         memset(&fa, 0, sizeof(fa));
-        fa.src = src; fa.dst = S->d_tmp_a;
+        fa.src = src; fa.dst = C->tmp_a;
         fa.nx = nx; fa.ny = ny; fa.nz = Lg->nloc;
         fa.axis = 0; fa.width = f->width; fa.taps = f->taps;
         fa.unit_factor = ufx;
         fa.n_glob = nzo; fa.off = 0;
         fa.z_lo = a; fa.z_hi = b;
-        rc = sift3d_hip_fir_x_scaled(&fa, d_scale_max, S->stream);
+        rc = sift3d_hip_fir_x_scaled(&fa, d_scale_max, C->stream);
         if (rc == 1)
             return 2;
         if (rc != SIFT3D_SUCCESS)
             return SIFT3D_FAILURE;
-    } else if (sh_fir(S, src, S->d_tmp_a, o, Lg->nloc, 0, f, ufx, 0, a, b, S->stream))
+    } else if (sh_fir(S, src, C->tmp_a, o, Lg->nloc, 0, f, ufx, 0, a, b, C->stream))
         return SIFT3D_FAILURE;
-    fused = ufy == 1.0f && ufz == 1.0f && sift3d_hip_fir_yz_u1_covers(S->d_tmp_a, dst, nx, ny, f->width, nzo);
-    zin = S->d_tmp_a;
+    fused = ufy == 1.0f && ufz == 1.0f && sift3d_hip_fir_yz_u1_covers(C->tmp_a, dst, nx, ny, f->width, nzo);
+    zin = C->tmp_a;
     if (!fused) {
-        if (sh_fir(S, S->d_tmp_a, S->d_tmp_b, o, Lg->nloc, 1, f, ufy, 0, a, b, S->stream))
+        if (sh_fir(S, C->tmp_a, C->tmp_b, o, Lg->nloc, 1, f, ufy, 0, a, b, C->stream))
             return SIFT3D_FAILURE;
-        zin = S->d_tmp_b;
+        zin = C->tmp_b;
     }
     /* interior planes need no halo: [ia, ib) */
     ia = exch && Lg->z0 > 0 ? a + reach : a;
@@ -486,10 +530,10 @@ static int sh_blur(sift3d_amd_sharded *S, int o, const float *src, const sh_leve
     if (ib < ia)
         ia = ib = a;                                     /* thin slab: everything after the exchange */
     if (exch) {
-        if (sift3d_hip_event_record(S->ev_x, S->stream) ||
-            sift3d_hip_stream_wait_event(S->comm_stream, S->ev_x) ||
+        if (sift3d_hip_event_record(C->ev_x, C->stream) ||
+            sift3d_hip_stream_wait_event(S->comm_stream, C->ev_x) ||
             sh_halo(S, zin, Lg, plane, reach, S->comm_stream) ||
-            sift3d_hip_event_record(S->ev_halo, S->comm_stream))
+            sift3d_hip_event_record(C->ev_halo, S->comm_stream))
             return SIFT3D_FAILURE;
     }
 #define SH_ZPASS(lo_, hi_)                                                                           \
@@ -497,16 +541,16 @@ static int sh_blur(sift3d_amd_sharded *S, int o, const float *src, const sh_leve
         if ((hi_) > (lo_)) {                                                                         \
             if (fused) {                                                                             \
                 rc = sift3d_hip_fir_yz_u1(zin, dst, nx, ny, Lg->nloc, f->taps, f->width, nzo,        \
-                                          Lg->off, (lo_), (hi_), S->stream);                         \
+                                          Lg->off, (lo_), (hi_), C->stream);                         \
                 if (rc != SIFT3D_SUCCESS)                                                            \
                     return SIFT3D_FAILURE;                                                           \
-            } else if (sh_fir(S, zin, dst, o, Lg->nloc, 2, f, ufz, Lg->off, (lo_), (hi_), S->stream)) \
+            } else if (sh_fir(S, zin, dst, o, Lg->nloc, 2, f, ufz, Lg->off, (lo_), (hi_), C->stream)) \
                 return SIFT3D_FAILURE;                                                               \
         }                                                                                            \
     } while (0)
     SH_ZPASS(ia, ib);
     if (exch) {
-        if (sift3d_hip_stream_wait_event(S->stream, S->ev_halo))
+        if (sift3d_hip_stream_wait_event(C->stream, C->ev_halo))
             return SIFT3D_FAILURE;
         SH_ZPASS(a, ia);
         SH_ZPASS(ib, b);
@@ -591,76 +635,121 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
             return SIFT3D_FAILURE;
         (void)a;        /* (im_scale itself: folded into the first blur below, or run there) */
     }
-    /* build_gpyr, sift.c:662-711 */
+    /* build_gpyr, sift.c:662-711 -- on three dependency chains, as the single-GPU path builds it
+     * (detect_on_device): octave o + 1 starts from level K of octave o (sift.c:696-704) and the levels after
+     * K feed nothing but their octave's DoG, so once level K of octave 0 exists the smaller octaves --
+     * short launches that cannot fill the device -- are built on a second stream BESIDE the last levels of
+     * octave 0, their own last levels on a third, and all are joined before the DoG stage.  The z-halo
+     * exchanges of all chains travel on the one communication stream in the order the host issues them
+     * (the same on every rank); the collective of the sharded -> replicated transition stays on the main
+     * stream, where every other collective of a step is issued. */
     sift3d_hip_event_record(S->ev0, S->stream);
-    for (o = 0; o < S->num_octaves; o++) {
-        if (o == 0) {
-            /* the first blur reads the raw slab and scales as it stages (im_scale folded into the x pass:
-             * the scaled image is not stored); where that x pass does not apply, scale first */
-            const sh_level *L0 = &S->G[0][0];
-            const int a0 = sh_sharded(S, 0) ? L0->z0 - L0->off : 0;
-            const size_t n_in = sh_plane(S, 0) * (size_t)(S->in_z1 - S->in_z0);
-            /* (d_raw holds the owned planes only: plane index a0 of the level buffer is its plane 0) */
-            int rc = sh_blur(S, 0, S->d_raw - (size_t)a0 * sh_plane(S, 0), L0, L0->t, &S->filt[0], S->d_scalars);
-            if (rc == 2) {
-                if (sift3d_hip_scale(S->d_raw, S->d_im + (size_t)a0 * sh_plane(S, 0), n_in, S->d_scalars, S->stream) ||
-                    sh_blur(S, 0, S->d_im, L0, L0->t, &S->filt[0], NULL))
+    {
+        const int forked = S->num_octaves > 1 && S->K + 1 < S->ngl;
+        const struct sh_chain *C0 = &S->chain[0];
+        for (o = 0; o < S->num_octaves; o++) {
+            const struct sh_chain *Ca = (o > 0 && forked) ? &S->chain[1] : C0;     /* levels 1 .. K */
+            const struct sh_chain *Cb = (o > 0 && forked) ? &S->chain[2] : C0;     /* levels K + 1 .. */
+            if (o == 0) {
+                /* the first blur reads the raw slab and scales as it stages (im_scale folded into the x
+                 * pass: the scaled image is not stored); where that x pass does not apply, scale first */
+                const sh_level *L0 = &S->G[0][0];
+                const int a0 = sh_sharded(S, 0) ? L0->z0 - L0->off : 0;
+                const size_t n_in = sh_plane(S, 0) * (size_t)(S->in_z1 - S->in_z0);
+                /* (d_raw holds the owned planes only: plane index a0 of the level buffer is its plane 0) */
+                int rc = sh_blur(S, C0, 0, S->d_raw - (size_t)a0 * sh_plane(S, 0), L0, L0->t, &S->filt[0],
+                                 S->d_scalars);
+                if (rc == 2) {
+                    if (sift3d_hip_scale(S->d_raw, S->d_im + (size_t)a0 * sh_plane(S, 0), n_in, S->d_scalars,
+                                         S->stream) ||
+                        sh_blur(S, C0, 0, S->d_im, L0, L0->t, &S->filt[0], NULL))
+                        return SIFT3D_FAILURE;
+                } else if (rc != SIFT3D_SUCCESS) {
                     return SIFT3D_FAILURE;
-            } else if (rc != SIFT3D_SUCCESS) {
-                return SIFT3D_FAILURE;
-            }
-        }
-        for (s = 1; s < S->ngl; s++)
-            if (sh_blur(S, o, S->G[o][s - 1].t, &S->G[o][s], S->G[o][s].t, &S->filt[s], NULL))
-                return SIFT3D_FAILURE;
-        if (o != S->num_octaves - 1) {
-            /* level max(s_end - 2, first_level) = Gaussian index K, sift.c:696-704 */
-            const sh_level *src = &S->G[o][S->K];
-            sh_level *dst = &S->G[o + 1][0];
-            const int mx = S->dims[o + 1][0], my = S->dims[o + 1][1], mzg = S->dims[o + 1][2];
-            const size_t pl_s = sh_plane(S, o), pl_d = sh_plane(S, o + 1);
-            if (sh_sharded(S, o) && !sh_sharded(S, o + 1)) {
-                /* transition to the replicated octaves: down-sample the owned planes into a
-                 * staging slab, all-gather the slabs (padded to the largest) */
-                int zb[SH_MAX_WORLD + 1], mxn = 1;
-                for (r = 0; r < S->world; r++) {
-                    zb[r] = S->b0[r] >> (o + 1);
-                    if (zb[r] > mzg) zb[r] = mzg;
                 }
-                zb[S->world] = mzg;
-                for (r = 0; r < S->world; r++)
-                    if (zb[r + 1] - zb[r] > mxn) mxn = zb[r + 1] - zb[r];
-                {
-                    const int z0 = zb[S->rank], z1 = zb[S->rank + 1];
-                    float *mine = S->d_stage, *all;
-                    const size_t slab = (size_t)mxn * pl_d;
-                    if (slab * (size_t)(S->world + 1) > S->stage_elems)
+            }
+            for (s = 1; s <= S->K && s < S->ngl; s++)
+                if (sh_blur(S, Ca, o, S->G[o][s - 1].t, &S->G[o][s], S->G[o][s].t, &S->filt[s], NULL))
+                    return SIFT3D_FAILURE;
+            if (forked) {
+                /* level K exists: the next octave (chain 1) and this octave's last levels (chain 2, or the
+                 * main stream for octave 0) go their own ways */
+                if (o == 0) {
+                    if (sift3d_hip_event_record(S->ev_fork, S->stream) ||
+                        sift3d_hip_stream_wait_event(S->oct_stream, S->ev_fork))
                         return SIFT3D_FAILURE;
-                    all = mine + slab;
-                    if (sift3d_hip_memset(mine, 0, slab * sizeof(float), S->stream))
-                        return SIFT3D_FAILURE;
-                    if (z1 > z0 && sift3d_hip_downsample2(src->t + (size_t)(2 * z0 - src->off) * pl_s,
-                                                          S->dims[o][0], S->dims[o][1], mine, mx, my,
-                                                          z1 - z0, S->stream))
-                        return SIFT3D_FAILURE;
-                    if (S->T.allgather(S->T.ctx, mine, all, slab * sizeof(float), S->stream))
-                        return SIFT3D_FAILURE;
+                } else if (sift3d_hip_event_record(S->ev_oct[o], Ca->stream) ||
+                           sift3d_hip_stream_wait_event(Cb->stream, S->ev_oct[o])) {
+                    return SIFT3D_FAILURE;
+                }
+            }
+            if (o != S->num_octaves - 1) {
+                /* level max(s_end - 2, first_level) = Gaussian index K, sift.c:696-704; on the stream that
+                 * builds the next octave */
+                void *ds = forked ? S->oct_stream : S->stream;
+                const sh_level *src = &S->G[o][S->K];
+                sh_level *dst = &S->G[o + 1][0];
+                const int mx = S->dims[o + 1][0], my = S->dims[o + 1][1], mzg = S->dims[o + 1][2];
+                const size_t pl_s = sh_plane(S, o), pl_d = sh_plane(S, o + 1);
+                if (sh_sharded(S, o) && !sh_sharded(S, o + 1)) {
+                    /* transition to the replicated octaves: down-sample the owned planes into a
+                     * staging slab, all-gather the slabs (padded to the largest) */
+                    int zb[SH_MAX_WORLD + 1], mxn = 1;
+                    for (r = 0; r < S->world; r++) {
+                        zb[r] = S->b0[r] >> (o + 1);
+                        if (zb[r] > mzg) zb[r] = mzg;
+                    }
+                    zb[S->world] = mzg;
                     for (r = 0; r < S->world; r++)
-                        if (zb[r + 1] > zb[r] &&
-                            sift3d_hip_memcpy_d2d(dst->t + (size_t)zb[r] * pl_d, all + (size_t)r * slab,
-                                                  (size_t)(zb[r + 1] - zb[r]) * pl_d * sizeof(float),
-                                                  S->stream))
+                        if (zb[r + 1] - zb[r] > mxn) mxn = zb[r + 1] - zb[r];
+                    {
+                        const int z0 = zb[S->rank], z1 = zb[S->rank + 1];
+                        float *mine = S->d_stage, *all;
+                        const size_t slab = (size_t)mxn * pl_d;
+                        if (slab * (size_t)(S->world + 1) > S->stage_elems)
                             return SIFT3D_FAILURE;
+                        all = mine + slab;
+                        if (sift3d_hip_memset(mine, 0, slab * sizeof(float), ds))
+                            return SIFT3D_FAILURE;
+                        if (z1 > z0 && sift3d_hip_downsample2(src->t + (size_t)(2 * z0 - src->off) * pl_s,
+                                                              S->dims[o][0], S->dims[o][1], mine, mx, my,
+                                                              z1 - z0, ds))
+                            return SIFT3D_FAILURE;
+                        /* the collective on the main stream (behind what that stream holds), the next
+                         * octave behind the collective */
+                        if (ds != S->stream && (sift3d_hip_event_record(S->ev_tr, ds) ||
+                                                sift3d_hip_stream_wait_event(S->stream, S->ev_tr)))
+                            return SIFT3D_FAILURE;
+                        if (S->T.allgather(S->T.ctx, mine, all, slab * sizeof(float), S->stream))
+                            return SIFT3D_FAILURE;
+                        for (r = 0; r < S->world; r++)
+                            if (zb[r + 1] > zb[r] &&
+                                sift3d_hip_memcpy_d2d(dst->t + (size_t)zb[r] * pl_d, all + (size_t)r * slab,
+                                                      (size_t)(zb[r + 1] - zb[r]) * pl_d * sizeof(float),
+                                                      S->stream))
+                                return SIFT3D_FAILURE;
+                        if (ds != S->stream && (sift3d_hip_event_record(S->ev_tr, S->stream) ||
+                                                sift3d_hip_stream_wait_event(ds, S->ev_tr)))
+                            return SIFT3D_FAILURE;
+                    }
+                } else {
+                    const int z0 = sh_sharded(S, o + 1) ? dst->z0 : 0, z1 = sh_sharded(S, o + 1) ? dst->z1 : mzg;
+                    if (z1 > z0 && sift3d_hip_downsample2(src->t + (size_t)(2 * z0 - src->off) * pl_s,
+                                                          S->dims[o][0], S->dims[o][1],
+                                                          dst->t + (size_t)(z0 - dst->off) * pl_d, mx, my,
+                                                          z1 - z0, ds))
+                        return SIFT3D_FAILURE;
                 }
-            } else {
-                const int z0 = sh_sharded(S, o + 1) ? dst->z0 : 0, z1 = sh_sharded(S, o + 1) ? dst->z1 : mzg;
-                if (z1 > z0 && sift3d_hip_downsample2(src->t + (size_t)(2 * z0 - src->off) * pl_s,
-                                                      S->dims[o][0], S->dims[o][1],
-                                                      dst->t + (size_t)(z0 - dst->off) * pl_d, mx, my,
-                                                      z1 - z0, S->stream))
-                    return SIFT3D_FAILURE;
             }
+            for (s = S->K + 1; s < S->ngl; s++)
+                if (sh_blur(S, Cb, o, S->G[o][s - 1].t, &S->G[o][s], S->G[o][s].t, &S->filt[s], NULL))
+                    return SIFT3D_FAILURE;
         }
+        if (forked && (sift3d_hip_event_record(S->ev_join, S->oct_stream) ||
+                       sift3d_hip_stream_wait_event(S->stream, S->ev_join) ||
+                       sift3d_hip_event_record(S->ev_join2, S->side_stream) ||
+                       sift3d_hip_stream_wait_event(S->stream, S->ev_join2)))
+            return SIFT3D_FAILURE;
     }
     sift3d_hip_event_record(S->ev1, S->stream);
 
