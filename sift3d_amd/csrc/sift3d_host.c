@@ -131,6 +131,7 @@ struct _sift3d_detector {
     unsigned char dog_free[64]; /* per octave: the last detect formed its DoG levels on the fly */
     float *d_scalars;      /* [0] input max, [1] count (as u32), [8 + o*ndl + s] dogmax, then
                             * [8 + (num_octaves + o)*ndl + s] their lower bounds (sift3d_hip_dogmax_sub) */
+    int t_pending;         /* stage events not yet read into t[]: 1 detect, 2 describe */
     int im_valid;          /* d_im holds the scaled image of the last detect call (else: see last_vol) */
     const float *last_vol; /* the last detect call's volume on the device (the caller's, or d_in) */
     int est0;              /* the large octaves' maxima gathered by their extrema sweeps (default; 0: a pass
@@ -1172,7 +1173,25 @@ void sift3d_free_detector(sift3d_detector *d)
     free(d);
 }
 
-const double *sift3d_amd_timings(const sift3d_detector *d) { return d->t; }
+/* stage seconds of the last calls; the device-side ones are read from the stage events here, not on the
+ * path of a step (both calls end with a stream synchronisation, so the events are complete) */
+const double *sift3d_amd_timings(const sift3d_detector *dc)
+{
+    sift3d_detector *d = (sift3d_detector *)dc;
+    if (d->t_pending & 1) {
+        d->t[0] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[0], d->ev[1]);
+        d->t[1] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[1], d->ev[2]);
+        d->t[2] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[2], d->ev[3]);
+        d->t[3] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[3], d->ev[4]);
+        d->t[4] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[4], d->ev[5]);
+        d->t[6] = d->t[1];
+        d->t[9] = d->yz_timed ? 1e-3 * sift3d_hip_event_elapsed_ms(d->ev_yz[0], d->ev_yz[1]) : 0.0;
+    }
+    if (d->t_pending & 2)
+        d->t[5] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[6], d->ev[7]);
+    d->t_pending = 0;
+    return d->t;
+}
 int sift3d_amd_num_candidates(const sift3d_detector *d) { return d->ncand; }
 
 /* max|DoG| of every level of the last detect call (the dogmax scan, sift.c:821-826): out[o * ndl + s],
@@ -1730,13 +1749,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     }
     d->have_pyramid = 1;
 
-    d->t[0] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[0], d->ev[1]);
-    d->t[1] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[1], d->ev[2]);
-    d->t[2] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[2], d->ev[3]);
-    d->t[3] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[3], d->ev[4]);
-    d->t[4] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[4], d->ev[5]);
-    d->t[6] = d->t[1];
-    d->t[9] = d->yz_timed ? 1e-3 * sift3d_hip_event_elapsed_ms(d->ev_yz[0], d->ev_yz[1]) : 0.0;
+    d->t_pending |= 1;                  /* (the stage events are read when sift3d_amd_timings asks) */
     d->t[7] = now_s() - t_start;
     return SIFT3D_SUCCESS;
 }
@@ -1953,7 +1966,7 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
         return SIFT3D_FAILURE;
     if (desc->keep_device)
         desc->d_num = (size_t)num;
-    d->t[5] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[6], d->ev[7]);
+    d->t_pending |= 2;
     d->t[8] = now_s() - t_start;
     return SIFT3D_SUCCESS;
 }
