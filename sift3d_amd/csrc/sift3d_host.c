@@ -148,7 +148,7 @@ struct _sift3d_detector {
     float *d_wlut;         /* per-level window-weight tables of the descriptor kernel */
     void *d_otab;          /* window tables + per-candidate sums of the orientation kernels */
     size_t otab_bytes;
-    sift3d_hip_kp *d_kp, *h_kp;
+    sift3d_hip_kp *h_kp;    /* the describe kernel's input list (page-locked; read by the kernel in place) */
     uint32_t kp_cap;
     int have_pyramid;
     int ncand;
@@ -1150,7 +1150,6 @@ void sift3d_free_detector(sift3d_detector *d)
     free_filters(d);
     sift3d_hip_free(d->d_in);
     sift3d_hip_free(d->d_cand);
-    sift3d_hip_free(d->d_kp);
     sift3d_hip_host_free(d->h_cand);
     sift3d_hip_host_free(d->h_R);
     sift3d_hip_host_free(d->h_keep);
@@ -1851,12 +1850,10 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
     }
     if ((uint32_t)num > d->kp_cap) {
         const uint32_t cap = (uint32_t)num + (uint32_t)num / 4 + 256;
-        sift3d_hip_free(d->d_kp);
         sift3d_hip_host_free(d->h_kp);
         d->kp_cap = 0;
-        d->d_kp = (sift3d_hip_kp *)sift3d_hip_malloc(sizeof(sift3d_hip_kp) * (size_t)cap);
         d->h_kp = (sift3d_hip_kp *)sift3d_hip_host_alloc(sizeof(sift3d_hip_kp) * (size_t)cap);
-        if (!d->d_kp || !d->h_kp)
+        if (!d->h_kp)
             return SIFT3D_FAILURE;
         d->kp_cap = cap;
     }

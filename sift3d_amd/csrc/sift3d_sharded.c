@@ -105,7 +105,7 @@ struct sift3d_amd_sharded {
     uint32_t cand_cap;
     void *d_xchg, *h_xchg;           /* all-gather staging (device + pinned host mirror) */
     size_t xchg_bytes;
-    sift3d_hip_kp *d_kp, *h_kp;
+    sift3d_hip_kp *h_kp;
     uint32_t kp_cap;
     int ncand;
     /* [0] pyramid (device s)  [1] detect wall  [2] describe wall  [3] DoG maxima + extrema (device s,
@@ -199,7 +199,7 @@ void sift3d_amd_sharded_free(sift3d_amd_sharded *S)
     sift3d_hip_free(S->d_levels); sift3d_hip_free(S->d_work); sift3d_hip_free(S->d_work2);
     sift3d_hip_free(S->d_cand);
     sift3d_hip_free(S->d_R); sift3d_hip_free(S->d_keep); sift3d_hip_free(S->d_xchg);
-    sift3d_hip_free(S->d_kp); sift3d_hip_free(S->d_wlut); sift3d_hip_free(S->d_otab);
+    sift3d_hip_free(S->d_wlut); sift3d_hip_free(S->d_otab);
     sift3d_hip_host_free(S->h_cand); sift3d_hip_host_free(S->h_R); sift3d_hip_host_free(S->h_keep);
     sift3d_hip_host_free(S->h_xchg); sift3d_hip_host_free(S->h_kp);
     sift3d_hip_event_destroy(S->ev_x); sift3d_hip_event_destroy(S->ev_halo);
@@ -1183,12 +1183,10 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
         return SIFT3D_SUCCESS;
     if ((uint32_t)n > S->kp_cap) {
         const uint32_t cap = (uint32_t)n + (uint32_t)n / 4 + 256;
-        sift3d_hip_free(S->d_kp);
         sift3d_hip_host_free(S->h_kp);
         S->kp_cap = 0;
-        S->d_kp = (sift3d_hip_kp *)sift3d_hip_malloc(sizeof(sift3d_hip_kp) * (size_t)cap);
         S->h_kp = (sift3d_hip_kp *)sift3d_hip_host_alloc(sizeof(sift3d_hip_kp) * (size_t)cap);
-        if (!S->d_kp || !S->h_kp)
+        if (!S->h_kp)
             return SIFT3D_FAILURE;
         S->kp_cap = cap;
     }
@@ -1237,10 +1235,11 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
         }
     }
     {
+        /* (the kernel reads a keypoint's record once, as its wave starts: from the page-locked list in place) */
         float *dev_view = (float *)sift3d_hip_host_device_ptr(desc->hist);
-        if (!dev_view ||
-            sift3d_hip_memcpy_h2d(S->d_kp, S->h_kp, sizeof(sift3d_hip_kp) * (size_t)n, S->stream) ||
-            sift3d_hip_describe_wlut(S->d_levels, S->num_octaves * S->ngl, S->d_kp, (uint32_t)n, dev_view,
+        const sift3d_hip_kp *kp_view = (const sift3d_hip_kp *)sift3d_hip_host_device_ptr(S->h_kp);
+        if (!dev_view || !kp_view ||
+            sift3d_hip_describe_wlut(S->d_levels, S->num_octaves * S->ngl, kp_view, (uint32_t)n, dev_view,
                                      S->d_wlut, S->stream) ||
             sift3d_hip_stream_sync(S->stream))
             return SIFT3D_FAILURE;
