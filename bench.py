@@ -289,6 +289,46 @@ def register_bench(a, torch, api, hip):
     print(json.dumps(out))
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N copies of this script as child processes
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run sets them), relay
+    their output, return non-zero if any rank fails.  The parent imports neither torch nor the library and
+    makes no HIP call: nothing is exec'd from a GPU-initialised process."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                try:
+                    code = p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    # a rank died: the others are inside a collective it will never join
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n"
+                                     % (procs.index(p), code))
+                    for q in pending:
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,6 +353,11 @@ def main():
                          "drop-in API, to measure the driver's own overhead")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started like the one-GPU run (`python bench.py --gpus N ...`), not under torch.distributed.run:
+        # this process starts the N ranks itself and never touches the GPU
+        raise SystemExit(launch_ranks(a.gpus))
+
     import torch
     import torch.distributed as dist
     from sift3d_amd import api, hip
@@ -321,7 +366,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % a.gpus)
+        raise SystemExit("--gpus %d, but WORLD_SIZE is %d" % (a.gpus, world))
     if not torch.cuda.is_available() or not api.device_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU path to measure")
     # SIFT3D_AMD_REHEARSE=1: all ranks share device 0 and talk through gloo -- a rehearsal of
@@ -332,10 +377,10 @@ def main():
     torch.cuda.set_device(local_rank)
     hip.lib().sift3d_hip_set_device(local_rank)
     if world > 1:
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # Control plane (the RCCL unique id, the barriers around the timed region, the max over ranks of a
+        # few host scalars): gloo.  The data plane -- halos, reductions, gathers -- is the library's OWN RCCL
+        # communicator (sift3d_amd_rccl_transport); no second RCCL communicator exists in the process.
+        dist.init_process_group("gloo")
 
     n = a.strong if a.strong else a.size
     nz_total = n if a.strong else n * world
@@ -392,7 +437,7 @@ def main():
 
         stats = lambda: dict(candidates=det.num_candidates(), keypoints=len(kp),  # noqa: E731
                              stage_s={k: round(v, 6) for k, v in det.timings().items()})
-        pyr_time = lambda: det.timings()["gauss_dev"]  # noqa: E731
+        pyr_time = lambda: (lambda t: (t["gauss_dev"], t.get("yz_last", 0.0)))(det.timings())  # noqa: E731
     else:
         # The slab driver in C (sift3d_amd/csrc/sift3d_sharded.c) over the library's own RCCL
         # communicator; rehearsals on one device stage the exchanges through gloo.
@@ -416,16 +461,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pyr = []
+    pyr, yz_in_step = [], []
     for _ in range(a.steps):
         step()
-        pyr.append(pyr_time())
+        pt_ = pyr_time()
+        if isinstance(pt_, tuple):
+            pyr.append(pt_[0])
+            yz_in_step.append(pt_[1])
+        else:
+            pyr.append(pt_)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cpu" if rehearse else "cuda", dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -434,12 +484,20 @@ def main():
         # stage seconds of the last step, max over ranks (so that a scaling curve can be read)
         bd = job.breakdown()
         keys = sorted(bd)
-        t = torch.tensor([bd[k] for k in keys], device="cpu" if rehearse else "cuda", dtype=torch.float64)
+        t = torch.tensor([bd[k] for k in keys], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         per_rank = {k: round(float(v), 6) for k, v in zip(keys, t.tolist())}
-    if rank != 0:
+    def _finish():
+        """Tear the ranks down in step: slab driver, the library's RCCL communicator, the process group."""
         if world > 1:
+            job.close()
+            dist.barrier()
+            if tr is not None:
+                tr.close()
             dist.destroy_process_group()
+
+    if rank != 0:
+        _finish()
         return
 
     ms_per_step = 1e3 * dt / a.steps
@@ -502,86 +560,96 @@ def main():
         torch.cuda.synchronize()
         th = (time.perf_counter() - t0) / a.steps
         assert len(kp2) == len(kp)
-        out["value_host_resident"] = {"value": round(voxels_per_step / 1e6 / th, 2), "unit": "Mvoxel/s",
-                                      "ms_per_step": round(1e3 * th, 3),
-                                      "note": "volume in pageable host memory, PCIe H2D inside the "
-                                              "timed region (sift3d_detect_keypoints on a "
-                                              "sift3d_image)"}
+        # (scalars: volume in pageable host memory, PCIe H2D inside the timed region --
+        # sift3d_detect_keypoints on a sift3d_image; never `value`)
+        out["value_host_resident"] = round(voxels_per_step / 1e6 / th, 2)
+        out["ms_per_step_host_resident"] = round(1e3 * th, 3)
         del im
     if world == 1 and not a.no_micro and not a.sharded and not a.strong and not rt:
         kb = kernel_microbench(torch, hip, n)
         # dominant kernel = the pipeline kernel with the longest launch
         dom = max((k for k in kb if k["in_pipeline"]), key=lambda k: k["avg_ms"])
-        tr = None
+        tbytes = None
         if traffic:
             # profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950
             # corrections applied by profiles/pmc_fir.py) is keyed by the kernel symbol
             sym = dom["kernel"].split(" (")[0]
             if sym in traffic:
-                tr = traffic[sym]["hbm_bytes"]
-        # `achieved` / `frac` price the ALGORITHMIC bytes (8 B per voxel and 1-D
-        # pass) against the HBM peak; `hbm_GBs` is what the kernel really moves (measured
-        # traffic / launch time): the fused y+z kernel keeps its intermediate on chip, so its
-        # HBM rate is about half its algorithmic rate.
-        out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"],
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": tr,
-                           "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / "
-                                             "WRITE_SIZE passes of this kernel, committed; not "
-                                             "measured in this run)",
-                           "hbm_GBs": round(tr / 1e9 / (dom["avg_ms"] * 1e-3), 1) if tr else None,
+                tbytes = traffic[sym]["hbm_bytes"]
+        # `achieved` / `frac` price the ALGORITHMIC bytes (8 B per voxel and 1-D pass)
+        # against the HBM peak, with the launch duration measured IN THE STEP: HIP events around that
+        # launch -- the last blur of octave 0 -- on the stream it runs on, median over the timed steps;
+        # there it shares the device with the streams that build octaves >= 1, which is also what the
+        # rocprofv3 kernel trace of a --no-micro run averages (profiles/).  `frac_alone` is the same kernel
+        # with the device to itself (the microbench leg).  `hbm_GBs` is what the kernel really moves
+        # (counter traffic / launch time): the fused y+z kernel keeps its intermediate on chip.
+        yz_ms = 1e3 * float(np.median(yz_in_step)) if yz_in_step and min(yz_in_step) > 0 else None
+        launch_ms = yz_ms if yz_ms else dom["avg_ms"]
+        ach = dom["algorithmic_GB"] / (launch_ms * 1e-3)
+        out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(ach, 1),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                           "traffic": tbytes,
+                           "avg_launch_ms": round(launch_ms, 4),
+                           "launch_timing": "in the step (median of %d steps)" % len(yz_in_step) if yz_ms
+                                            else "kernel alone (no in-step events)",
+                           "frac_alone": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4),
+                           "avg_launch_ms_alone": dom["avg_ms"],
                            "algorithmic_bytes_per_launch": int(dom["algorithmic_GB"] * 1e9),
-                           "avg_launch_ms": dom["avg_ms"], "pyramid": pyramid, "kernels": kb}
-        # avg_launch_ms is the kernel ALONE on the device (this leg's launches).  Inside the step
-        # the same launch -- the last blur of octave 0 -- shares the device with the streams that
-        # build octaves >= 1 (HIP events on its own stream, last step of the timed region); the
-        # rocprofv3 average in profiles/ is the mix of both kinds of launch.
-        yz_last = out.get("stage_s", {}).get("yz_last")
-        if yz_last:
-            out["roofline"]["avg_launch_ms_in_pipeline"] = round(1e3 * yz_last, 4)
-            out["roofline"]["frac_in_pipeline"] = round(dom["algorithmic_GB"] / yz_last / HBM_PEAK_GBS, 4)
-            out["roofline"]["in_pipeline_note"] = ("in the step this launch overlaps the octave >= 1 "
-                                                   "streams; avg_launch_ms is the kernel alone")
+                           "hbm_GBs": round(tbytes / 1e9 / (launch_ms * 1e-3), 1) if tbytes else None,
+                           "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                             "passes of this kernel, committed; not measured in this run)"}
+        if pyramid:
+            # the metric BASELINE.json names: achieved HBM GB/s on the whole Gaussian pyramid build
+            out["roofline"].update(pyramid_frac=pyramid["frac"], pyramid_ms=round(1e3 * pyramid["seconds"], 4),
+                                   pyramid_GBs=pyramid["achieved"],
+                                   pyramid_algorithmic_GB=pyramid["algorithmic_GB"])
+        details = {"kernels": kb, "pyramid": pyramid}
         dpath = os.path.join(ROOT, "profiles", "describe_model.json")
         if os.path.exists(dpath):
             try:
                 dm = json.load(open(dpath))
                 dsec = out.get("stage_s", {}).get("describe")
                 if dsec and dm.get("valu_insts"):
-                    # k_describe is bound by instruction issue (VALU and the LDS pipe), not by HBM.  Two
-                    # readings, side by side: what the hardware counters of the committed profile say for
-                    # this kernel (instruction and LDS-array-cycle counts are properties of the code and
-                    # the workload; the seconds are this run's), and the issue model that prices every
-                    # LDS instruction at its back-to-back microbenchmark cost.
+                    # k_describe is bound by instruction issue (VALU and the LDS pipe), not by HBM: what the
+                    # hardware counters of the committed profile say for this kernel (instruction and
+                    # LDS-array-cycle counts are properties of the code and the workload; the seconds are
+                    # this run's)
                     cu_cycles = dsec * 2.4e9 * 256
                     simd_rate = 256 * 4 * 2.4e9 / dm.get("cycles_per_valu", 2.5)
                     dm["seconds"] = dsec
                     dm["valu_frac"] = round(dm["valu_insts"] / dsec / simd_rate, 4)
                     dm["lds_array_frac"] = round(dm.get("lds_array_cycles", 0) / cu_cycles, 4)
-                    lm = dm.get("lds_issue_model") or {}
-                    dm["lds_issue_model_frac"] = (round(lm["seconds_if_lds_bound"] / dsec, 4)
-                                                  if lm.get("seconds_if_lds_bound") else None)
                     if dm.get("wave_quad_cycles"):
                         w = dm["wave_quad_cycles"]
                         dm["wave_time_split"] = {"waiting_at_s_waitcnt": round(dm.get("wait_any", 0) / w, 3),
                                                  "issue_stalled": round(dm.get("wait_inst_any", 0) / w, 3),
                                                  "issue_stalled_on_lds": round(dm.get("wait_inst_lds", 0) / w, 3)}
-                    dm["bound"] = ("instruction issue: VALU %.2f and LDS array %.2f busy by the counters (neither "
-                                   "saturated: the rest is latency the 4 waves per SIMD do not hide); the "
-                                   "LDS-issue model prices the LDS pipe at %.2f"
-                                   % (dm["valu_frac"], dm["lds_array_frac"], dm["lds_issue_model_frac"] or 0))
                     dm["frac"] = max(dm["valu_frac"], dm["lds_array_frac"])
-                    out["roofline"]["describe"] = dm
+                    details["describe"] = dm
+                    out["roofline"].update(describe_ms=round(1e3 * dsec, 3), describe_valu_frac=dm["valu_frac"],
+                                           describe_lds_array_frac=dm["lds_array_frac"])
             except Exception:
                 pass
+        out["details"] = details
     else:
         out["roofline"] = dict(pyramid or {}, kernel="Gaussian pyramid (all k_fir_* launches)",
                                traffic=None)
+        if pyramid:
+            out["roofline"].update(pyramid_frac=pyramid["frac"], pyramid_ms=round(1e3 * pyramid["seconds"], 4),
+                                   pyramid_GBs=pyramid["achieved"])
+        if yz_in_step and min(yz_in_step) > 0:
+            # (no microbench leg: the in-step launch of the dominant kernel, as the default run reports it)
+            yz_ms = 1e3 * float(np.median(yz_in_step))
+            out["roofline"].update(dominant_kernel="k_fir_yz_u1<8, ...> (last blur of octave 0)",
+                                   dominant_avg_launch_ms=round(yz_ms, 4),
+                                   dominant_frac=round(16.0 * n ** 3 / 1e9 / (yz_ms * 1e-3) / HBM_PEAK_GBS, 4))
     if not a.no_cpu and world == 1:          # the CPU leg runs at N = 1 only
         out["cpu_baseline"] = cpu_baseline()
+    if "details" in out:                     # the long per-kernel lists go last
+        out["details"] = out.pop("details")
     print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    sys.stdout.flush()
+    _finish()
 
 
 if __name__ == "__main__":

@@ -203,6 +203,22 @@ SIFT3D_AMD_API int sift3d_amd_rccl_transport(sift3d_amd_transport *out, int worl
                                              const void *id128);
 SIFT3D_AMD_API void sift3d_amd_rccl_transport_free(sift3d_amd_transport *t);
 
+/* Rehearsal / test transport: the `world` ranks are THREADS of one process (one slab driver each, on the
+ * same device), exchanging device-to-device.  Stream-ordered with the completion semantics of
+ * ncclSend / ncclRecv / ncclAllGather / ncclAllReduce and no host-side stream synchronisation
+ * (sift3d_amd/csrc/sift3d_thread_transport.c): (pointer, event) pairs travel through a host mailbox, the
+ * copies run on the receiver's stream behind the sender's `ready` event, the sender's stream waits for the
+ * receiver's `consumed` event.  An error in the driver's event edges between its streams therefore shows
+ * on one GPU as a wrong result, as it would over RCCL on eight.  _abort wakes every rank waiting in an
+ * exchange (their calls fail) -- for a caller whose rank has given up. */
+typedef struct sift3d_amd_thread_group sift3d_amd_thread_group;
+SIFT3D_AMD_API sift3d_amd_thread_group *sift3d_amd_thread_group_create(int world);
+SIFT3D_AMD_API void sift3d_amd_thread_group_free(sift3d_amd_thread_group *);
+SIFT3D_AMD_API void sift3d_amd_thread_group_abort(sift3d_amd_thread_group *);
+SIFT3D_AMD_API int sift3d_amd_thread_transport(sift3d_amd_transport *out, sift3d_amd_thread_group *,
+                                               int rank);
+SIFT3D_AMD_API void sift3d_amd_thread_transport_free(sift3d_amd_transport *t);
+
 /* sift3d_detect_keypoints + sift3d_extract_descriptors (sift.c:1217-1249, 1615-1635) on ONE
  * nx*ny*nz volume cut into `world` Z-slabs; results equal the single-GPU ones bit for bit.
  * `params` supplies thresholds, scales, the number of keypoint levels per octave and the extrema
@@ -254,6 +270,8 @@ SIFT3D_AMD_API int sift3d_hip_memcpy_d2d(void *d_dst, const void *d_src, size_t 
 SIFT3D_AMD_API int sift3d_hip_memcpy2d_d2h(void *h_dst, size_t dst_pitch, const void *d_src,
                                            size_t src_pitch, size_t width, size_t height, void *stream);
 SIFT3D_AMD_API int sift3d_hip_stream_wait_event(void *stream, void *ev);
+/* d_dst[i] = max over r of d_rows[r * n + i] (the reduction step of the thread transport's all-reduce) */
+SIFT3D_AMD_API int sift3d_hip_max_rows(float *d_dst, const float *d_rows, int nrows, int n, void *stream);
 SIFT3D_AMD_API int sift3d_hip_memset(void *d_dst, int byte, size_t bytes, void *stream);
 SIFT3D_AMD_API void *sift3d_hip_stream_create(void);
 SIFT3D_AMD_API void *sift3d_hip_stream_create_high(void);   /* highest dispatch priority */

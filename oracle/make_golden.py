@@ -315,6 +315,24 @@ def main():
         jobs["g5_256"] = lambda: end_to_end(
             "g5_256", so.synth_survey(256), desc_stride=64, store_levels=False,
             input_spec=dict(gen="survey", n=256, nblob=12800))
+    # descriptors at large sigma0 (sift.c:1453-1456: the window grows with sd^3, a bin receives ~30x
+    # the terms it gets at the default 1.6) -- only on request (the reference needs minutes)
+    if a.only and "g3_sigma3" in a.only.split(","):
+        jobs["g3_sigma3"] = lambda: end_to_end(
+            "g3_sigma3", so.synth_lattice(96, seed=13), store_levels=False,
+            params=dict(sigma0=3.0, peak_thresh=0.03, corner_thresh=0.3),
+            input_spec=dict(gen="lattice", n=96, seed=13))
+    if a.only and "g3_sigma5" in a.only.split(","):
+        jobs["g3_sigma5"] = lambda: end_to_end(
+            "g3_sigma5", so.synth_survey(96), store_levels=False,
+            params=dict(sigma0=5.0, peak_thresh=0.02, corner_thresh=0.2),
+            input_spec=dict(gen="survey", n=96))
+    if a.only and "g5_slab8" in a.only.split(","):
+        # BASELINE configs[3]'s slab geometry at 1/16 of its voxels: 256 x 256 x 1024 (eight 128-plane
+        # Z-slabs, o_shard = 2) -- the sharded GPU tests compare with THIS, not with the single-GPU API
+        jobs["g5_slab8"] = lambda: end_to_end_digest(
+            "g5_256x256x1024", so.synth_lattice((256, 256, 1024), seed=11), stride=53,
+            input_spec=dict(gen="lattice", n=[256, 256, 1024], seed=11))
     if a.only and "g5_512" in a.only.split(","):
         # BASELINE configs[2] (the bench workload): ~10 min of reference CPU time, ~10 GB
         jobs["g5_512"] = lambda: end_to_end_digest(

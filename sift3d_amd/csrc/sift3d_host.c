@@ -27,6 +27,7 @@
 #include <time.h>
 #include <zlib.h>
 #include <omp.h>
+#include <pthread.h>
 
 #include "../../include/sift3d/imutil.h"
 #include "../../include/sift3d/sift.h"
@@ -155,6 +156,7 @@ struct _sift3d_detector {
     double t[SIFT3D_AMD_NUM_TIMINGS];
 };
 
+static pthread_mutex_t g_mesh_lock = PTHREAD_MUTEX_INITIALIZER;
 static unsigned char g_mesh_ready[64];   /* per device: the __constant__ tables live on ONE device */
 
 static double now_s(void)
@@ -756,13 +758,15 @@ static int upload_mesh(void)
         { 9, 11, 7 }, { 9, 7, 1 }, { 1, 7, 6 }, { 3, 6, 7 }, { 3, 7, 11 }, { 3, 11, 2 },
         { 3, 2, 10 }, { 3, 10, 6 } };
     float rec[NFACES * SIFT3D_HIP_FACE_FLOATS];
-    int i, j, k;
-    {
-        const int dev = sift3d_hip_current_device();
-        if (dev < 0 || dev >= (int)sizeof(g_mesh_ready))
-            return SIFT3D_FAILURE;
-        if (g_mesh_ready[dev])
-            return SIFT3D_SUCCESS;
+    int i, j, k, rc;
+    const int dev = sift3d_hip_current_device();
+    if (dev < 0 || dev >= (int)sizeof(g_mesh_ready))
+        return SIFT3D_FAILURE;
+    /* (detectors and slab drivers may be created from several threads at once) */
+    pthread_mutex_lock(&g_mesh_lock);
+    if (g_mesh_ready[dev]) {
+        pthread_mutex_unlock(&g_mesh_lock);
+        return SIFT3D_SUCCESS;
     }
     for (i = 0; i < NFACES; i++) {
         float v[3][3], a[3], b[3], n[3];
@@ -803,10 +807,11 @@ static int upload_mesh(void)
         for (k = 0; k < 3; k++)
             r[16 + k] = (float)faces[i][k];
     }
-    if (sift3d_hip_set_mesh(rec))
-        return SIFT3D_FAILURE;
-    g_mesh_ready[sift3d_hip_current_device()] = 1;
-    return SIFT3D_SUCCESS;
+    rc = sift3d_hip_set_mesh(rec);
+    if (rc == SIFT3D_SUCCESS)
+        g_mesh_ready[dev] = 1;
+    pthread_mutex_unlock(&g_mesh_lock);
+    return rc ? SIFT3D_FAILURE : SIFT3D_SUCCESS;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1172,22 +1177,30 @@ void sift3d_free_detector(sift3d_detector *d)
     free(d);
 }
 
+/* seconds between two stage events; NaN when the pair is not a completed pair of one call (a failed
+ * query must not read as a duration) */
+static double stage_seconds(void *a, void *b)
+{
+    const double ms = sift3d_hip_event_elapsed_ms(a, b);
+    return ms >= 0.0 ? 1e-3 * ms : (double)NAN;
+}
+
 /* stage seconds of the last calls; the device-side ones are read from the stage events here, not on the
  * path of a step (both calls end with a stream synchronisation, so the events are complete) */
 const double *sift3d_amd_timings(const sift3d_detector *dc)
 {
     sift3d_detector *d = (sift3d_detector *)dc;
     if (d->t_pending & 1) {
-        d->t[0] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[0], d->ev[1]);
-        d->t[1] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[1], d->ev[2]);
-        d->t[2] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[2], d->ev[3]);
-        d->t[3] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[3], d->ev[4]);
-        d->t[4] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[4], d->ev[5]);
+        d->t[0] = stage_seconds(d->ev[0], d->ev[1]);
+        d->t[1] = stage_seconds(d->ev[1], d->ev[2]);
+        d->t[2] = stage_seconds(d->ev[2], d->ev[3]);
+        d->t[3] = stage_seconds(d->ev[3], d->ev[4]);
+        d->t[4] = stage_seconds(d->ev[4], d->ev[5]);
         d->t[6] = d->t[1];
-        d->t[9] = d->yz_timed ? 1e-3 * sift3d_hip_event_elapsed_ms(d->ev_yz[0], d->ev_yz[1]) : 0.0;
+        d->t[9] = d->yz_timed ? stage_seconds(d->ev_yz[0], d->ev_yz[1]) : 0.0;
     }
     if (d->t_pending & 2)
-        d->t[5] = 1e-3 * sift3d_hip_event_elapsed_ms(d->ev[6], d->ev[7]);
+        d->t[5] = stage_seconds(d->ev[6], d->ev[7]);
     d->t_pending = 0;
     return d->t;
 }
@@ -1401,13 +1414,16 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                              !d->num_octaves;
     const double t_start = now_s();
     uint32_t count = 0;
-    int o, s, attempt, side;
+    int o, s, attempt, side, im_stored = 0;
 
     /* set_im_SIFT3D, sift.c:629-659 */
     d->have_im = 1;
     d->nx = nx; d->ny = ny; d->nz = nz;
     d->units[0] = ux; d->units[1] = uy; d->units[2] = uz;
     d->have_pyramid = 0;
+    d->im_valid = 0;                    /* (both are set again only by a call that succeeds) */
+    d->last_vol = NULL;
+    d->t_pending &= ~1;                 /* the stage events are re-recorded from here on */
     if (dims_changed && resize_detector(d)) {
         d->have_im = 0;
         return SIFT3D_FAILURE;
@@ -1435,14 +1451,12 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
         level_units(d, 0, lu);
         rc = blur_level(d, d_vol, d->d_g[0], d->odims[0], lu, &d->filt[0], d->stream, d->d_tmp_a,
                         d->d_tmp_b, 0, d->d_scalars);
-        d->im_valid = 0;
-        d->last_vol = d_vol;
         if (rc == 2) {
             if (sift3d_hip_scale(d_vol, d->d_im, n0, d->d_scalars, d->stream) ||
                 blur_level(d, d->d_im, d->d_g[0], d->odims[0], lu, &d->filt[0], d->stream, d->d_tmp_a,
                            d->d_tmp_b, 0, NULL))
                 return SIFT3D_FAILURE;
-            d->im_valid = 1;
+            im_stored = 1;
         } else if (rc != SIFT3D_SUCCESS) {
             return SIFT3D_FAILURE;
         }
@@ -1703,8 +1717,10 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
         pre[0] = 0;
 #pragma omp parallel num_threads(nt)
         {
-            const int t = omp_get_thread_num();
-            const size_t lo = (size_t)count * t / nt, hi = (size_t)count * (t + 1) / nt;
+            /* the team may be smaller than asked for (a caller inside its own parallel region,
+             * OMP_THREAD_LIMIT, OMP_DYNAMIC): the list is cut by the team's real size */
+            const int nth = omp_get_num_threads(), t = omp_get_thread_num();
+            const size_t lo = (size_t)count * t / nth, hi = (size_t)count * (t + 1) / nth;
             size_t q, jj = 0;
             for (q = lo; q < hi; q++)
                 jj += d->h_keep[q] != 0;
@@ -1713,9 +1729,9 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
 #pragma omp single
             {
                 int u;
-                for (u = 0; u < nt; u++)
+                for (u = 0; u < nth; u++)
                     pre[u + 1] += pre[u];
-                rc = kp_store_resize(kp, pre[nt]);
+                rc = kp_store_resize(kp, pre[nth]);
             }
             /* (implicit barrier) */
             if (rc == SIFT3D_SUCCESS) {
@@ -1747,6 +1763,11 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
             return SIFT3D_FAILURE;
     }
     d->have_pyramid = 1;
+    d->im_valid = im_stored;
+    /* The scaled image is formed on demand (sift3d_amd_copy_level, which = 2) from the volume -- but only from
+     * the detector's OWN upload buffer: a caller's device pointer is not kept beyond the call (it may be
+     * freed or reused the moment this returns). */
+    d->last_vol = d_vol == d->d_in ? d_vol : NULL;
 
     d->t_pending |= 1;                  /* (the stage events are read when sift3d_amd_timings asks) */
     d->t[7] = now_s() - t_start;
@@ -1874,8 +1895,8 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
         memset(cnt, 0, sizeof(cnt));
 #pragma omp parallel num_threads(nt)
         {
-            const int t = omp_get_thread_num();
-            const size_t lo = (size_t)num * t / nt, hi = (size_t)num * (t + 1) / nt;
+            const int nth = omp_get_num_threads(), t = omp_get_thread_num();  /* (nth <= nt: see above) */
+            const size_t lo = (size_t)num * t / nth, hi = (size_t)num * (t + 1) / nth;
             size_t q;
             for (q = lo; q < hi; q++)
                 cnt[t][kp->buf[q].s + 1]++;
@@ -1885,7 +1906,7 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
                 size_t pos = 0;
                 int lv, u;
                 for (lv = nlv - 1; lv >= 0; lv--)
-                    for (u = 0; u < nt; u++) {
+                    for (u = 0; u < nth; u++) {
                         start[u][lv] = pos;
                         pos += cnt[u][lv];
                     }
@@ -1932,6 +1953,7 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
             return SIFT3D_FAILURE;
         desc->d_cap = desc->cap;
     }
+    d->t_pending &= ~2;
     sift3d_hip_event_record(d->ev[6], d->stream);
     /* (the kernel reads the 64-byte record of a keypoint once, as its wave starts: straight from the
      * page-locked host list -- no copy, no DMA set-up between the host loops and the launch) */
@@ -1972,16 +1994,21 @@ int sift3d_amd_copy_level(const sift3d_detector *d, int which, int o, int s, flo
 {
     const float *src;
     size_t n;
-    if (!d->num_octaves || !d->stream)
+    if (!d->num_octaves || !d->stream || !d->have_pyramid)
         return SIFT3D_FAILURE;
     if (which == 2) {
         o = 0;
         if (!d->im_valid) {
-            /* the scaled image was folded into the first blur: form it now (im_scale) from the last
-             * volume -- for sift3d_amd_detect_keypoints_device that is the CALLER's buffer, which must
-             * still hold the volume */
+            /* the scaled image was folded into the first blur: form it now (im_scale) from the volume
+             * the detector uploaded itself.  After sift3d_amd_detect_keypoints_device the volume was the
+             * CALLER's and no pointer to it was kept: the scaled image is then not available. */
             const size_t n0 = (size_t)d->odims[0][0] * d->odims[0][1] * d->odims[0][2];
-            if (!d->last_vol || sift3d_hip_scale(d->last_vol, d->d_im, n0, d->d_scalars, d->stream))
+            if (!d->last_vol) {
+                ERR("sift3d_amd_copy_level: the scaled input image is not retained after "
+                    "sift3d_amd_detect_keypoints_device (the volume belongs to the caller) \n");
+                return SIFT3D_FAILURE;
+            }
+            if (sift3d_hip_scale(d->last_vol, d->d_im, n0, d->d_scalars, d->stream))
                 return SIFT3D_FAILURE;
         }
         src = d->d_im;

@@ -936,8 +936,8 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
             }
 #pragma omp parallel num_threads(nt)
             {
-                const int t = omp_get_thread_num();
-                const size_t lo = (size_t)count * t / nt, hi = (size_t)count * (t + 1) / nt;
+                const int nth = omp_get_num_threads(), t = omp_get_thread_num();  /* (the team's real size) */
+                const size_t lo = (size_t)count * t / nth, hi = (size_t)count * (t + 1) / nth;
                 int32_t *mine = tc + (size_t)t * 2 * nkey;
                 size_t q;
                 for (q = lo; q < hi; q++) {
@@ -996,8 +996,8 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
             pre[0] = 0;
 #pragma omp parallel num_threads(nt)
             {
-                const int t = omp_get_thread_num();
-                const size_t lo = (size_t)count * t / nt, hi = (size_t)count * (t + 1) / nt;
+                const int nth = omp_get_num_threads(), t = omp_get_thread_num();
+                const size_t lo = (size_t)count * t / nth, hi = (size_t)count * (t + 1) / nth;
                 size_t q, jj = 0;
                 for (q = lo; q < hi; q++)
                     jj += S->h_keep[q] != 0;
@@ -1006,7 +1006,7 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
 #pragma omp single
                 {
                     int u;
-                    for (u = 0; u < nt; u++)
+                    for (u = 0; u < nth; u++)
                         pre[u + 1] += pre[u];
                 }
                 /* (implicit barrier) */
@@ -1122,13 +1122,13 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
         /* the keypoints this rank owns, in list order: counted and placed by a few threads, each on a
          * contiguous part of the list */
         const int nt = host_threads((size_t)num);
-        size_t pre[HOST_THREADS_MAX + 1];
+        size_t pre[HOST_THREADS_MAX + 1], total = 0;
         int bad = 0;
         pre[0] = 0;
 #pragma omp parallel num_threads(nt) reduction(| : bad)
         {
-            const int t = omp_get_thread_num();
-            const size_t lo = (size_t)num * t / nt, hi = (size_t)num * (t + 1) / nt;
+            const int nth = omp_get_num_threads(), t = omp_get_thread_num();  /* (the team's real size) */
+            const size_t lo = (size_t)num * t / nth, hi = (size_t)num * (t + 1) / nth;
             size_t q, jj = 0;
 #define SH_OWN(k_) (S->world == 1 || ((k_)->zd >= (double)S->bounds[(k_)->o][S->rank] &&          \
                                       (k_)->zd < (double)S->bounds[(k_)->o][S->rank + 1]))
@@ -1145,8 +1145,9 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
 #pragma omp single
             {
                 int u;
-                for (u = 0; u < nt; u++)
+                for (u = 0; u < nth; u++)
                     pre[u + 1] += pre[u];
+                total = pre[nth];
             }
             /* (implicit barrier) */
             jj = pre[t];
@@ -1161,7 +1162,7 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
         }
         if (bad)
             return SIFT3D_FAILURE;
-        n = (int)pre[nt];
+        n = (int)total;
     }
     *n_own = n;
     desc->nx = S->nx; desc->ny = S->ny; desc->nz = S->nz;
@@ -1179,6 +1180,7 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
         desc->cap = cap;
     }
     desc->num = (size_t)n;
+    desc->d_num = 0;                 /* (rows are rewritten: a device copy kept by an earlier call is stale) */
     if (!n)
         return SIFT3D_SUCCESS;
     if ((uint32_t)n > S->kp_cap) {
@@ -1201,8 +1203,8 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
         memset(cnt, 0, sizeof(cnt));
 #pragma omp parallel num_threads(nt)
         {
-            const int t = omp_get_thread_num();
-            const size_t lo = (size_t)n * t / nt, hi = (size_t)n * (t + 1) / nt;
+            const int nth = omp_get_num_threads(), t = omp_get_thread_num();
+            const size_t lo = (size_t)n * t / nth, hi = (size_t)n * (t + 1) / nth;
             size_t q;
             for (q = lo; q < hi; q++)
                 cnt[t][kp->buf[own_idx[q]].s]++;
@@ -1212,7 +1214,7 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
                 size_t p = 0;
                 int lv, u;
                 for (lv = S->K - 1; lv >= 0; lv--)
-                    for (u = 0; u < nt; u++) {
+                    for (u = 0; u < nth; u++) {
                         start[u][lv] = p;
                         p += cnt[u][lv];
                     }
@@ -1373,3 +1375,6 @@ void sift3d_amd_rccl_transport_free(sift3d_amd_transport *t)
     free(R);
     t->ctx = NULL;
 }
+
+/* ranks as threads of one process: the stream-ordered rehearsal transport */
+#include "sift3d_thread_transport.c"

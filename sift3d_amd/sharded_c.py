@@ -43,6 +43,15 @@ def _lib():
         L.sift3d_amd_rccl_transport.argtypes = [C.POINTER(Transport), C.c_int, C.c_int, vp]
         L.sift3d_amd_rccl_transport_free.argtypes = [C.POINTER(Transport)]
         L.sift3d_amd_rccl_transport_free.restype = None
+        L.sift3d_amd_thread_group_create.restype = vp
+        L.sift3d_amd_thread_group_create.argtypes = [C.c_int]
+        L.sift3d_amd_thread_group_free.argtypes = [vp]
+        L.sift3d_amd_thread_group_free.restype = None
+        L.sift3d_amd_thread_group_abort.argtypes = [vp]
+        L.sift3d_amd_thread_group_abort.restype = None
+        L.sift3d_amd_thread_transport.argtypes = [C.POINTER(Transport), vp, C.c_int]
+        L.sift3d_amd_thread_transport_free.argtypes = [C.POINTER(Transport)]
+        L.sift3d_amd_thread_transport_free.restype = None
         L.sift3d_amd_sharded_create.restype = vp
         L.sift3d_amd_sharded_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Transport), vp,
                                                 C.c_double, C.c_double, C.c_double]
@@ -224,6 +233,49 @@ class ThreadTransport:
 
     def close(self):
         pass
+
+
+class StreamThreadGroup:
+    """The C side's group of N thread-ranks (sift3d_amd_thread_group): mailboxes and events of the
+    STREAM-ORDERED thread transport.  `barrier.abort()` mirrors ThreadGroup's interface for the callers
+    that give up on an exception."""
+
+    class _Abort:
+        def __init__(self, g):
+            self.g = g
+
+        def abort(self):
+            if self.g.h:
+                _lib().sift3d_amd_thread_group_abort(self.g.h)
+
+    def __init__(self, world):
+        self.world = world
+        self.h = _lib().sift3d_amd_thread_group_create(world)
+        if not self.h:
+            raise RuntimeError("sift3d_amd_thread_group_create failed")
+        self.barrier = StreamThreadGroup._Abort(self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            _lib().sift3d_amd_thread_group_free(self.h)
+            self.h = None
+
+
+class StreamThreadTransport:
+    """N ranks as N threads of one process, exchanging through the library's stream-ordered thread
+    transport (sift3d_thread_transport.c): device-to-device copies ordered by HIP events only -- the
+    completion semantics of ncclSend/ncclRecv, NO host-side stream synchronisation.  A missing event edge
+    between the slab driver's streams shows here as a wrong result on one GPU."""
+
+    def __init__(self, group, rank):
+        self.g, self.rank, self.world = group, rank, group.world
+        self.t = Transport()
+        if _lib().sift3d_amd_thread_transport(C.byref(self.t), group.h, rank) != 0:
+            raise RuntimeError("sift3d_amd_thread_transport failed")
+
+    def close(self):
+        if self.t.ctx:
+            _lib().sift3d_amd_thread_transport_free(C.byref(self.t))
 
 
 class RcclTransport:

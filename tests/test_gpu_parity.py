@@ -11,6 +11,7 @@ reproducible -- summation order (two half-wave partial histograms), so they agre
 float ulps per element, checked ELEMENTWISE against 1e-5 (util.rel_err has no absolute term).
 """
 import json
+import os
 
 import numpy as np
 import pytest
@@ -19,6 +20,7 @@ from tests import util
 from tests.test_oracle_golden import check_detect_against_golden
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 RTOL = 1e-5  # north_star: "descriptor and orientation floats within 1e-5 relative"
 
@@ -255,7 +257,8 @@ def _run_api(api, vol, units=(1, 1, 1), params=None, device_input=False):
 
 
 @pytest.mark.parametrize("name", ["g3_64", "g3_70x50x41", "g3_aniso", "g3_params",
-                                  "g3_lattice48", "g5_128", "g3_cuboid64", "g3_cuboid_params"])
+                                  "g3_lattice48", "g5_128", "g3_cuboid64", "g3_cuboid_params",
+                                  "g3_sigma3", "g3_sigma5"])
 def test_detect_describe_golden(gpu, oracle_mod, name):
     """Against the reference's own outputs: every pyramid level (sha1 digests + small levels
     in full), candidate count, the keypoint list incl. the stale-strength quirk, R,
@@ -591,3 +594,61 @@ def test_repeated_runs_are_bitwise_identical(gpu):
                   hashlib.sha1(np.ascontiguousarray(k["R"]).tobytes()).hexdigest(),
                   det.num_candidates(), len(k)))
     assert len(seen) == 1 and next(iter(seen))[3] > 100
+
+
+def test_host_loops_with_a_smaller_openmp_team(gpu):
+    """The host loops between the stages (candidate -> keypoint compaction, the launch-order sort of
+    describe) cut their lists by the size of the OpenMP team they REALLY got: under OMP_THREAD_LIMIT=3
+    (a team smaller than the eight threads asked for, as inside a caller's own parallel region) the
+    results must be those of the full team.  OMP_THREAD_LIMIT is read when libgomp starts: subprocess."""
+    import hashlib
+    import subprocess
+    import sys
+    api, hip, torch = gpu
+    code = (
+        "import hashlib, numpy as np, torch\n"
+        "from sift3d_amd import api, hip\n"
+        "n = 256\n"
+        "vol = torch.empty((n, n, n), device='cuda'); hip.synth_lattice(vol, 0, 21)\n"
+        "det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()\n"
+        "assert det.detect_keypoints_device(vol.data_ptr(), n, n, n, kp) == 0\n"
+        "assert det.extract_descriptors(kp, desc) == 0\n"
+        "k = kp.records()\n"
+        "h = lambda a: hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()\n"
+        "print('RESULT', det.num_candidates(), len(k), h(k['xd']), h(k['strength']), h(k['R']), "
+        "h(desc.to_mat_rm()))\n")
+    got = {}
+    for limit in ("3", None):
+        env = dict(os.environ)
+        env.pop("OMP_THREAD_LIMIT", None)
+        if limit:
+            env["OMP_THREAD_LIMIT"] = limit
+        out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
+        assert line, out.stdout[-2000:]
+        got[limit] = line[0].split()[1:]
+    assert int(got["3"][0]) > 8192 and int(got["3"][1]) > 4096      # both host loops ran multi-threaded
+    assert got["3"] == got[None]
+
+
+def test_scaled_image_is_not_formed_from_a_borrowed_pointer(gpu, oracle_mod):
+    """sift3d_amd_copy_level(which = 2) forms the scaled input image (im_scale, imutil.c:698-713) on
+    demand from the volume the detector uploaded ITSELF; after sift3d_amd_detect_keypoints_device the
+    volume was the caller's, no pointer to it is kept, and the call fails instead of reading memory the
+    caller may have freed."""
+    api, hip, torch = gpu
+    vol = oracle_mod.synth_survey(48)
+    det, kp = api.Detector(), api.KeypointStore()
+    assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
+    want = det.level(2, 0, 0)
+    np.testing.assert_array_equal(want, (vol / np.abs(vol).max()).astype(np.float32))
+    t = torch.from_numpy(vol).cuda()
+    assert det.detect_keypoints_device(t.data_ptr(), 48, 48, 48, kp) == 0
+    del t
+    with pytest.raises((RuntimeError, IndexError)):
+        det.level(2, 0, 0)
+    np.testing.assert_array_equal(det.level(0, 0, -1).shape, (48, 48, 48))   # the pyramid itself stays readable
+    assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
+    np.testing.assert_array_equal(det.level(2, 0, 0), want)

@@ -214,33 +214,36 @@ def test_config4_1024_sharded_equals_single_gpu():
     torch.cuda.empty_cache()
 
 
-def test_config4_geometry_eight_ranks():
-    """BASELINE configs[3]'s real geometry: EIGHT Z-slabs.  256 x 256 x 1024 gives every rank the
-    128 planes (octave 0) and 64 planes (octave 1, against a ~40-plane window halo) it has at
-    1024^3, o_shard = 2 and the sharded -> replicated transition at octave 2.  The eight ranks are
-    eight threads of this process (the pool allows at most 6 processes on the card), each with its
-    own C slab driver, exchanging through ThreadTransport; every rank's result must equal the
-    single-GPU drop-in API bit for bit."""
+def _run_thread_ranks(world, dims, transport, det_kw=None, seed=5, synth_on_device=False):
+    """`world` C slab drivers as threads of THIS process on the one device; returns one dict per rank.
+    transport: "stream" = the library's stream-ordered thread transport (event-ordered device copies, the
+    completion semantics of ncclSend/ncclRecv, no host-side stream sync), "host" = ThreadTransport
+    (drains the stream around every exchange)."""
     import threading
-    import torch
-    from sift3d_amd import api, hip, sharded_c
-    if not torch.cuda.is_available():
-        pytest.fail("GPU test selected but no HIP device is visible")
-    world, dims = 8, (256, 256, 1024)
+    from sift3d_amd import api, sharded_c
     nx, ny, nz = dims
-    group = sharded_c.ThreadGroup(world)
+    group = sharded_c.StreamThreadGroup(world) if transport == "stream" else sharded_c.ThreadGroup(world)
+    make = sharded_c.StreamThreadTransport if transport == "stream" else sharded_c.ThreadTransport
+    vol = None if synth_on_device else api.synth_lattice(dims, seed=seed)
     out, err = [None] * world, []
 
     def run(rank):
         try:
-            job = sharded_c.CShardedSift3D(nx, ny, nz, sharded_c.ThreadTransport(group, rank))
-            job.synth(seed=11)
+            det = api.Detector(**det_kw) if det_kw else None
+            tr = make(group, rank)
+            job = sharded_c.CShardedSift3D(nx, ny, nz, tr, detector=det)
+            if synth_on_device:
+                job.synth(seed=seed)
+            else:
+                z0, z1 = job.in_own
+                job.set_local_volume(vol[z0:z1])
             job.detect()
             idx, desc = job.describe()
             out[rank] = dict(kp=job.keypoints(), idx=idx.copy(), own=job.in_own, o_shard=job.o_shard,
                              num_octaves=job.num_octaves, ncand=job.ncand,
                              mat=desc.to_mat_rm() if len(idx) else np.zeros((0, 771), np.float32))
             job.close()
+            tr.close()
         except Exception as e:  # noqa: BLE001
             err.append((rank, repr(e)))
             try:
@@ -253,8 +256,86 @@ def test_config4_geometry_eight_ranks():
         t.start()
     for t in th:
         t.join(900)
+    if transport == "stream":
+        group.close()
     assert not err, err
     assert all(o is not None for o in out)
+    return out
+
+
+@pytest.mark.parametrize("world,dims,det_kw", [
+    (2, (64, 72, 256), None), (3, (48, 48, 320), None), (4, (64, 64, 512), None),
+    (2, (130, 126, 244), None), (2, (64, 72, 256), dict(cuboid_extrema=True)),
+    (3, (50, 46, 330), dict(num_kp_levels=4, cuboid_extrema=True, peak_thresh=0.05))])
+def test_c_slab_driver_over_stream_ordered_transport(world, dims, det_kw):
+    """The configurations of test_c_slab_driver_equals_single_gpu with the exchanges ordered by HIP
+    events ALONE (sift3d_thread_transport.c: what ncclSend/ncclRecv guarantee and no more): every halo
+    exchange on the communication stream must be fenced against the chain streams that produce and
+    consume its planes by the driver's own events -- a missing edge is a bit difference here."""
+    import torch
+    from sift3d_amd import api
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    res = _run_thread_ranks(world, dims, "stream", det_kw)
+    vol = api.synth_lattice(dims, seed=5)
+    det, kp, desc = api.Detector(**(det_kw or {})), api.KeypointStore(), api.DescriptorStore()
+    assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
+    assert det.extract_descriptors(kp, desc) == 0
+    k, m = kp.records(), desc.to_mat_rm()
+    assert len(k) > 5
+    covered = np.zeros(len(k), int)
+    for g in res:
+        assert g["ncand"] == det.num_candidates() and g["o_shard"] >= 1
+        for f in ("o", "s", "xd", "yd", "zd", "sd", "strength", "R"):
+            np.testing.assert_array_equal(g["kp"][f], k[f], err_msg=f)
+        np.testing.assert_array_equal(g["mat"], m[g["idx"]])
+        covered[g["idx"]] += 1
+    np.testing.assert_array_equal(covered, 1)
+
+
+def _check_against_reference_fixture(g, kp, mat_rows, idx, ncand):
+    """A rank's results against the reference's own run of the volume (tests/golden/g5_256x256x1024.npz,
+    made by oracle/make_golden.py from the unmodified reference): keypoint fields and R by digest,
+    descriptor rows of this rank by their 8 projections (every row) and the sampled rows elementwise."""
+    import json
+    from tests import util
+    dig = json.loads(str(g["digests"]))
+    assert ncand == int(g["ncand"]) and len(kp) == int(g["nkp"])
+    assert util.digest(np.stack([kp["o"], kp["s"]], 1)) == dig["kp_os"]
+    xyzsd = np.stack([kp[f] for f in ("xd", "yd", "zd", "sd")], 1)
+    assert util.digest(xyzsd) == dig["kp_xyzsd"]
+    st = int(g["stride"])
+    np.testing.assert_array_equal(np.stack([kp["o"], kp["s"]], 1)[::st], g["kp_os_s"])
+    np.testing.assert_array_equal(xyzsd[::st], g["kp_xyzsd_s"])
+    np.testing.assert_array_equal(kp["strength"][::st], g["kp_strength_s"])
+    assert util.digest(kp["strength"]) == dig["kp_strength"]
+    assert util.digest(np.ascontiguousarray(kp["R"])) == dig["kp_R"]
+    if len(idx):
+        h = mat_rows[:, 3:]
+        util.assert_desc_projection(h, g["desc_proj"][idx], rtol=1e-5)
+        samp = np.nonzero(idx % st == 0)[0]
+        if len(samp):
+            assert util.rel_err(h[samp], g["desc_hist_s"][idx[samp] // st]) <= 1e-5
+
+
+@pytest.mark.parametrize("transport", ["stream", "host"])
+def test_config4_geometry_eight_ranks(transport):
+    """BASELINE configs[3]'s real geometry: EIGHT Z-slabs.  256 x 256 x 1024 gives every rank the
+    128 planes (octave 0) and 64 planes (octave 1, against a ~40-plane window halo) it has at
+    1024^3, o_shard = 2 and the sharded -> replicated transition at octave 2.  The eight ranks are
+    eight threads of this process (the pool allows at most 6 processes on the card), each with its
+    own C slab driver.  Every rank's result must equal (a) the REFERENCE's own run of this volume
+    (tests/golden/g5_256x256x1024.npz) and (b) the single-GPU drop-in API bit for bit -- over the
+    stream-ordered transport (exchanges ordered by events only, as over RCCL) and over the
+    host-synchronous one."""
+    import torch
+    from sift3d_amd import api, hip
+    from tests import util
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    world, dims = 8, (256, 256, 1024)
+    nx, ny, nz = dims
+    out = _run_thread_ranks(world, dims, transport, seed=11, synth_on_device=True)
     vol = torch.empty((nz, ny, nx), device="cuda")
     hip.synth_lattice(vol, 0, 11)
     torch.cuda.synchronize()
@@ -263,10 +344,13 @@ def test_config4_geometry_eight_ranks():
     assert det.extract_descriptors(kp, desc) == 0
     k, m = kp.records(), desc.to_mat_rm()
     assert len(k) > 5000
+    ref = util.load("g5_256x256x1024") if util.have("g5_256x256x1024") else None
+    assert ref is not None, "tests/golden/g5_256x256x1024.npz is missing"
     covered = np.zeros(len(k), int)
     for r, g in enumerate(out):
         assert g["own"] == (128 * r, 128 * (r + 1)) and g["o_shard"] == 2 and g["num_octaves"] == 6
         assert g["ncand"] == det.num_candidates()
+        _check_against_reference_fixture(ref, g["kp"], g["mat"], g["idx"], g["ncand"])
         for f in ("o", "s", "xd", "yd", "zd", "sd", "strength", "R"):
             np.testing.assert_array_equal(g["kp"][f], k[f], err_msg="rank %d field %s" % (r, f))
         np.testing.assert_array_equal(g["mat"], m[g["idx"]])
@@ -274,6 +358,50 @@ def test_config4_geometry_eight_ranks():
     np.testing.assert_array_equal(covered, 1)
     del det, vol
     torch.cuda.empty_cache()
+
+
+def _worker_fixture(rank, world, port, dims, seed, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from sift3d_amd import sharded_c
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
+                            world_size=world)
+    try:
+        job = sharded_c.CShardedSift3D(dims[0], dims[1], dims[2], sharded_c.DistTransport())
+        job.synth(seed=seed)
+        job.detect()
+        idx, desc = job.describe()
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), kp=job.keypoints(), idx=idx,
+                 mat=desc.to_mat_rm(), ncand=job.ncand, o_shard=job.o_shard)
+        job.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_slabs_against_reference_fixture():
+    """Two ranks (processes, exchanges staged through gloo) on the 256 x 256 x 1024 volume, compared with
+    the REFERENCE's own run of it (tests/golden/g5_256x256x1024.npz), not with this library's single-GPU
+    path: 78 466 candidates -> 21 180 keypoints, keypoint fields and R by digest, every descriptor row
+    of a rank by its projections."""
+    import torch
+    import torch.multiprocessing as mp
+    from tests import util
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    ref = util.load("g5_256x256x1024")
+    world, dims = 2, (256, 256, 1024)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_fixture, args=(world, _free_port(), dims, 11, d), nprocs=world, join=True)
+        res = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(world)]
+    covered = np.zeros(int(ref["nkp"]), int)
+    for g in res:
+        assert int(g["o_shard"]) >= 3
+        _check_against_reference_fixture(ref, g["kp"], g["mat"], g["idx"], int(g["ncand"]))
+        covered[g["idx"]] += 1
+    np.testing.assert_array_equal(covered, 1)
 
 
 def _worker_rccl1(rank, world, port, dims, outdir):
