@@ -62,6 +62,13 @@ sift3d_amd_detector_set_cuboid_extrema(sift3d_detector *det, int on);
  * sift3d_hip_extrema_gauss6_est_phase).  Same candidates either way; an A/B switch for tests and profiles. */
 SIFT3D_AMD_API int
 sift3d_amd_detector_set_dogmax_pass(sift3d_detector *det, int on);
+/* Descriptor accumulation (sift3d_extract_descriptors): 0 (default) = automatic: keypoints whose window
+ * holds more than ~1.9e5 voxels -- sigma0 * 2^(s/K) above ~2.9 voxels, never with the default parameters --
+ * are computed in the reference's accumulation order (their histograms are the reference's bit for bit),
+ * the others by the fast two-histogram commit (within 1e-5 relative, elementwise); 1 = every keypoint in
+ * the reference's order (bit-exact descriptors, ~1.5x the time); -1 = never. */
+SIFT3D_AMD_API int
+sift3d_amd_detector_set_exact_descriptors(sift3d_detector *det, int mode);
 /* max|DoG| of every DoG level of the last detect call, out[octave * levels + level] (the values
  * detect_extrema scales peak_thresh with, sift.c:821-829); returns their number, -1 on failure. */
 SIFT3D_AMD_API int
@@ -513,6 +520,14 @@ sift3d_hip_describe_wlut(const sift3d_hip_level *d_levels, int nlevels, const si
 SIFT3D_AMD_API int
 sift3d_hip_describe_wlut2(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
                           uint32_t n, float *d_hist, float *d_hist2, float *d_wlut, void *stream);
+/* The same with the first n_exact records computed in the reference's accumulation ORDER and term
+ * arithmetic (one histogram, voxels added in scan order, rounded products, sequential double norm): those
+ * histograms are the reference's bit for bit, at ~1.5x the time per window voxel.  For windows so wide that
+ * a bin receives enough terms for any other summation order to drift past 1e-5 relative of the reference's
+ * own sequential float sums (sift.c:1371-1373); see sift3d_amd_detector_set_exact_descriptors. */
+SIFT3D_AMD_API int
+sift3d_hip_describe_ex(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp, uint32_t n,
+                       uint32_t n_exact, float *d_hist, float *d_hist2, float *d_wlut, void *stream);
 
 /* Icosahedron face table for the descriptor kernel (init_geometry, sift.c:148-259;
  * per-face constants of cart2bary, sift.c:276-297).  20 records of

@@ -74,6 +74,7 @@ def lib():
         "sift3d_amd_image_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
         "sift3d_amd_detector_set_cuboid_extrema": (C.c_int, [vp, C.c_int]),
         "sift3d_amd_detector_set_dogmax_pass": (C.c_int, [vp, C.c_int]),
+        "sift3d_amd_detector_set_exact_descriptors": (C.c_int, [vp, C.c_int]),
         "sift3d_amd_detector_dogmax": (C.c_int, [vp, vp, C.c_int]),
         "sift3d_amd_copy_level": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, _i32p]),
         "sift3d_amd_keypoint_store_size": (C.c_int, [vp]),
@@ -312,13 +313,13 @@ class Detector:
     """sift3d_detector (reference: sift3d/sift.h:24-111)."""
 
     def __init__(self, peak_thresh=None, corner_thresh=None, num_kp_levels=None, sigma_n=None,
-                 sigma0=None, cuboid_extrema=None):
+                 sigma0=None, cuboid_extrema=None, exact_descriptors=None):
         self.h = lib().sift3d_make_detector()
         if not self.h:
             raise MemoryError("sift3d_make_detector")
         for name, v in (("sigma_n", sigma_n), ("sigma0", sigma0), ("peak_thresh", peak_thresh),
                         ("corner_thresh", corner_thresh), ("num_kp_levels", num_kp_levels),
-                        ("cuboid_extrema", cuboid_extrema)):
+                        ("cuboid_extrema", cuboid_extrema), ("exact_descriptors", exact_descriptors)):
             if v is not None and getattr(self, "set_" + name)(v) != 0:
                 raise ValueError("sift3d_detector_set_%s(%r) failed" % (name, v))
 
@@ -348,6 +349,11 @@ class Detector:
     def set_cuboid_extrema(self, on):
         """Run-time form of the reference's compile-time CUBOID_EXTREMA (sift.c:24)."""
         return lib().sift3d_amd_detector_set_cuboid_extrema(self.h, int(bool(on)))
+
+    def set_exact_descriptors(self, mode):
+        """0: automatic (wide windows in the reference's accumulation order), 1: always (descriptors bit-exact
+        with the reference), -1: never."""
+        return lib().sift3d_amd_detector_set_exact_descriptors(self.h, int(mode))
 
     def set_dogmax_pass(self, on):
         """A/B switch: octave 0's dogmax scan as a pass of its own (True) or gathered by the extrema sweep."""

@@ -170,8 +170,19 @@ __global__ __launch_bounds__(256) void k_desc_wlut(const sift3d_hip_level *__res
 
 constexpr int DWAVES = 4;   // keypoints (waves) per workgroup; they share the read-only tables
 
+// EXACT: the reference's accumulation ORDER and term arithmetic, for windows so large that a bin receives
+// enough terms for any other order to drift past 1e-5 of the reference's own (float, sequential) sums --
+// see "Accumulation order" above.  One histogram; the rounds of half-wave 0 (voxels 0..15 of a pass) run
+// first, then those of half-wave 1 (voxels 16..31), the idle half-wave adding into the second histogram
+// region, which is scratch here: every bin receives its terms in the reference's scan order (sift.c:96-108:
+// z, y, x).  A term is fl(fl(mag * w_cell) * bary) added with a plain add (sift.c:1371-1373), the magnitude a
+// correctly rounded sqrtf (sift.c:1331), the sum of squares of normalize_desc a sequential double sum in
+// element order (sift.c:1407-1416): the histogram is the reference's bit for bit.  Twice the commit rounds:
+// ~1.5x the time per window voxel.
+template <bool EXACT>
 __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level *__restrict__ levels,
-                                                 const sift3d_hip_kp *__restrict__ kps, uint32_t n,
+                                                 const sift3d_hip_kp *__restrict__ kps, uint32_t first,
+                                                 uint32_t n,
                                                  float *__restrict__ out, float *__restrict__ out2,
                                                  const float *__restrict__ wlut DESC_ABLATE_ARG)
 {
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     for (int i = lane; i < 2 * HIST_LDS; i += 64)
         hist[i] = 0.0f;
     __syncthreads();              // the only workgroup barrier: from here on the waves are independent
-    const uint32_t ki = blockIdx.x * DWAVES + wv;
+    const uint32_t ki = first + blockIdx.x * DWAVES + wv;
     if (ki >= n)
         return;
     const sift3d_hip_kp K = kps[ki];
@@ -247,8 +258,13 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     const int half = lane >> 5, l5 = lane & 31;
     const int pc = l5 < 24 ? l5 / 3 : 0, pj = l5 < 24 ? l5 - 3 * pc : 0;
     const int pdx = (pc >> 2) & 1, pdy = (pc >> 1) & 1, pdz = pc & 1;
-    // byte offset of this lane's cell corner, in this half-wave's histogram
-    const int coff4 = 4 * (pdx + 4 * pdy + 16 * pdz) + half * (HIST_LDS * 4);
+    // byte offset of this lane's cell corner, in this half-wave's histogram (EXACT: in THE histogram while
+    // this half-wave's rounds run -- sequence A: half-wave 0, sequence B: half-wave 1 --, else in the scratch
+    // region)
+    const int corner4 = 4 * (pdx + 4 * pdy + 16 * pdz);
+    const int coff_a = corner4 + (EXACT ? (half == 0 ? 0 : HIST_LDS * 4) : half * (HIST_LDS * 4));
+    const int coff_b = corner4 + (half == 1 ? 0 : HIST_LDS * 4);
+    (void)coff_b;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     uint32_t qhead = 0, qtail = 0; // wave-uniform
@@ -368,15 +384,14 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
 #define DESC_OPT 7
 #endif
 #if DESC_OPT & 1
-#define COMMIT_VAL(m, b) 0.0f
-#define COMMIT_ADD(old, val, m, b) __builtin_fmaf(m, b, old)
+#define COMMIT_ADD(old, m, b) (EXACT ? (old) + (m) * (b) : __builtin_fmaf(m, b, old))
 #else
-#define COMMIT_VAL(m, b) ((m) * (b))
-#define COMMIT_ADD(old, val, m, b) ((old) + (val))
+#define COMMIT_ADD(old, m, b) ((old) + (m) * (b))
 #endif
 // a value is computed in the slice that names it here (not sunk to its first use in a later one)
 #define KEEP(v) asm volatile("" ::"v"(v))
-#define COMMIT_BEGIN()                                                                        \
+#define COMMIT_BEGIN(coff)                                                                    \
+    const int coff4 = (coff);                                                                 \
     int4 cb4 = *reinterpret_cast<const int4 *>(&ab[pj][hb]);                                   \
     float4 cw4 = *reinterpret_cast<const float4 *>(&mw[pc][hb]);                               \
     float4 cx4 = *reinterpret_cast<const float4 *>(&bw[pj][hb]);                               \
@@ -392,8 +407,6 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         const int mb_[4] = { cb4.x, cb4.y, cb4.z, cb4.w };                                    \
         const float mv_[4] = { cw4.x, cw4.y, cw4.z, cw4.w }, bv_[4] = { cx4.x, cx4.y, cx4.z, cx4.w }; \
         float *bin_ = reinterpret_cast<float *>(reinterpret_cast<char *>(hist) + (mb_[(u) & 3] + coff4)); \
-        const float val_ = COMMIT_VAL(mv_[(u) & 3], bv_[(u) & 3]);        /* sift.c:1371-1373 */ \
-        (void)val_;                                                                           \
         float old_ = 0.0f;                                                                    \
         if (!DESC_ABLATE(1))                                                                  \
             old_ = *bin_;                                                                     \
@@ -401,13 +414,20 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         { __VA_ARGS__ }                                                                       \
         SB();                                                                                 \
         if (!DESC_ABLATE(1))                                                                  \
-            *bin_ = COMMIT_ADD(old_, val_, mv_[(u) & 3], bv_[(u) & 3]);                       \
+            *bin_ = COMMIT_ADD(old_, mv_[(u) & 3], bv_[(u) & 3]);      /* sift.c:1371-1373 */ \
         if (((u) & 3) == 3) {                                                                 \
             cb4 = nb4;                                                                        \
             cw4 = nw4;                                                                        \
             cx4 = nx4;                                                                        \
         }                                                                                     \
         SB();                                                                                 \
+    }
+    // EXACT: the same 16 rounds for half-wave 1's voxels (sequence B), after half-wave 0's
+#define CHAIN_B()                                                                             \
+    if (EXACT) {                                                                              \
+        COMMIT_BEGIN(coff_b);                                                                 \
+        ROUND(0, ) ROUND(1, ) ROUND(2, ) ROUND(3, ) ROUND(4, ) ROUND(5, ) ROUND(6, ) ROUND(7, ) \
+        ROUND(8, ) ROUND(9, ) ROUND(10, ) ROUND(11, ) ROUND(12, ) ROUND(13, ) ROUND(14, ) ROUND(15, ) \
     }
     // One batch: phase A of `cnt` (<= 64) voxels whose samples were fetched one batch ago (cv,
     // pk), woven into the two commit passes of the previous batch (records in rp), as are the
@@ -438,7 +458,7 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         // ================= pass 0: rounds of voxels 0..31  ||  window, gradient, face
         commit_write(0);
         {
-            COMMIT_BEGIN();
+            COMMIT_BEGIN(coff_a);
             ROUND(0, x = B.xs + (pk & 1023); y = B.ys + ((pk >> 10) & 1023); z = B.zs + (pk >> 20);
                      dx = ((float)x - K.cx) * L.ux; KEEP(dx);)             // sift.c:102-104
             ROUND(1, dy = ((float)y - K.cy) * L.uy; dz = ((float)z - K.cz) * L.uz; KEEP(dy); KEEP(dz);
@@ -492,6 +512,7 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
                               fminf(b0, fminf(b1, b2)) > 2e-5f;)
             ROUND(15, )
         }
+        CHAIN_B();
         if (__builtin_expect(__ballot(live && !found) != 0ull, 0)) {
             bool open = live && !found;
 #pragma unroll 1
@@ -513,7 +534,7 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         // cell weights, this batch's records
         commit_write(1);
         {
-            COMMIT_BEGIN();
+            COMMIT_BEGIN(coff_a);
             int nx_, ny_, nzl_, qv_;
             gfloat_p np_;
             float mag, fx, fy, fz;
@@ -542,7 +563,8 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
             // values behind them are finite), barycentrics 0 (0 * NaN would be NaN); their bin
             // addresses stay valid ones.
 #if DESC_OPT & 2
-            ROUND(4, mag = __builtin_amdgcn_sqrtf(m2); mag = live && found ? mag : 0.0f;) // sift.c:1331 (1 ulp)
+            ROUND(4, mag = EXACT ? sqrtf(m2) : __builtin_amdgcn_sqrtf(m2);               // sift.c:1331 (else: 1 ulp)
+                     mag = live && found ? mag : 0.0f;)
 #else
             ROUND(4, mag = sqrtf(m2); mag = live && found ? mag : 0.0f;)               // sift.c:1331
 #endif
@@ -576,15 +598,19 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
             ROUND(14, )
             ROUND(15, )
         }
+        CHAIN_B();
         prefetch_weight();
     };
     // the commit passes of the last batch (nothing left to weave in)
     auto commit_tail = [&](int pass) {
         const int hb = half * 16;
         commit_write(pass);
-        COMMIT_BEGIN();
-        ROUND(0, ) ROUND(1, ) ROUND(2, ) ROUND(3, ) ROUND(4, ) ROUND(5, ) ROUND(6, ) ROUND(7, )
-        ROUND(8, ) ROUND(9, ) ROUND(10, ) ROUND(11, ) ROUND(12, ) ROUND(13, ) ROUND(14, ) ROUND(15, )
+        {
+            COMMIT_BEGIN(coff_a);
+            ROUND(0, ) ROUND(1, ) ROUND(2, ) ROUND(3, ) ROUND(4, ) ROUND(5, ) ROUND(6, ) ROUND(7, )
+            ROUND(8, ) ROUND(9, ) ROUND(10, ) ROUND(11, ) ROUND(12, ) ROUND(13, ) ROUND(14, ) ROUND(15, )
+        }
+        CHAIN_B();
     };
 
     // The reference scans the whole bounding box of the sphere (sift.c:96-108).  Every voxel
@@ -731,18 +757,30 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     // double in element order; here every lane sums its 12-13 slots and the 64 partial sums are
     // combined by a fixed butterfly (reproducible; the double sum agrees to ~1e-16 relative).
     const float trunc = 0.2f * 128.0f / 768.0f;                               // sift.c:45
-    for (int i = lane; i < HIST_USED; i += 64)
-        hist[i] = hist[i] + hist[HIST_LDS + i];
-    wave_sync();
+    if (!EXACT) {
+        for (int i = lane; i < HIST_USED; i += 64)
+            hist[i] = hist[i] + hist[HIST_LDS + i];
+        wave_sync();
+    }
     for (int pass = 0; pass < 2; pass++) {
         double norm = 0.0;
-        for (int i = lane; i < HIST_USED; i += 64) {
-            const float el = hist[i];                                         // unused slots hold 0
-            norm += (double)el * (double)el;
-        }
+        if (EXACT) {
+            // the reference's own order (hists, then bins: sift.c:1407-1416); every lane adds the same values
+            for (int c = 0; c < 64; c++)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-            norm += __shfl_xor(norm, o, 64);
+                for (int b = 0; b < 12; b++) {
+                    const float el = hist[c_bin_off[b] + c];
+                    norm += (double)el * (double)el;
+                }
+        } else {
+            for (int i = lane; i < HIST_USED; i += 64) {
+                const float el = hist[i];                                     // unused slots hold 0
+                norm += (double)el * (double)el;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                norm += __shfl_xor(norm, o, 64);
+        }
         norm = sqrt(norm) + 2.220446049250313e-16;                            // DBL_EPSILON
         const float inv = (float)(1.0 / norm);                                // 1.0f / norm
         wave_sync();
@@ -905,20 +943,34 @@ size_t sift3d_hip_describe_wlut_floats(int nlevels)
     return nlevels > 0 ? (size_t)nlevels * WL_STRIDE : 0;
 }
 
+// records [0, n_exact) take the reference-order kernel, [n_exact, n) the fast one
 static int describe_launch(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d_kp, uint32_t n,
-                           float *d_hist, float *d_hist2, const float *d_wlut, void *stream)
+                           uint32_t n_exact, float *d_hist, float *d_hist2, const float *d_wlut,
+                           void *stream)
 {
+    if (n_exact > n)
+        n_exact = n;
 #ifdef SIFT3D_AMD_DIAG
     // diagnostic build only (wrong results): 1 skips the commit, 2 the whole batch -- used by
     // profiles/ scripts to attribute the kernel's time to scan / per-voxel terms / commit
     static int ablate = getenv("SIFT3D_AMD_DESC_ABLATE") ? atoi(getenv("SIFT3D_AMD_DESC_ABLATE")) : 0;
-    hipLaunchKernelGGL(k_describe, dim3((n + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
-                       (hipStream_t)stream, d_levels, d_kp, n, d_hist, d_hist2, d_wlut, ablate);
+#define DESC_ABLATE_PASS , ablate
 #else
-    hipLaunchKernelGGL(k_describe, dim3((n + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
-                       (hipStream_t)stream, d_levels, d_kp, n, d_hist, d_hist2, d_wlut);
+#define DESC_ABLATE_PASS
 #endif
-    LAUNCH_CHECK();
+    if (n_exact) {
+        hipLaunchKernelGGL(k_describe<true>, dim3((n_exact + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
+                           (hipStream_t)stream, d_levels, d_kp, 0u, n_exact, d_hist, d_hist2,
+                           d_wlut DESC_ABLATE_PASS);
+        LAUNCH_CHECK();
+    }
+    if (n > n_exact) {
+        hipLaunchKernelGGL(k_describe<false>, dim3((n - n_exact + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
+                           (hipStream_t)stream, d_levels, d_kp, n_exact, n, d_hist, d_hist2,
+                           d_wlut DESC_ABLATE_PASS);
+        LAUNCH_CHECK();
+    }
+#undef DESC_ABLATE_PASS
     return SIFT3D_SUCCESS;
 }
 
@@ -927,19 +979,26 @@ int sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d
 {
     if (!n)
         return SIFT3D_SUCCESS;
-    return describe_launch(d_levels, d_kp, n, d_hist, nullptr, nullptr, stream);
+    return describe_launch(d_levels, d_kp, n, 0, d_hist, nullptr, nullptr, stream);
+}
+
+int sift3d_hip_describe_ex(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
+                           uint32_t n, uint32_t n_exact, float *d_hist, float *d_hist2, float *d_wlut,
+                           void *stream)
+{
+    if (!n)
+        return SIFT3D_SUCCESS;
+    if (!d_wlut || nlevels < 1)
+        return describe_launch(d_levels, d_kp, n, n_exact, d_hist, d_hist2, nullptr, stream);
+    hipLaunchKernelGGL(k_desc_wlut, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, d_levels, nlevels,
+                       d_wlut);
+    return describe_launch(d_levels, d_kp, n, n_exact, d_hist, d_hist2, d_wlut, stream);
 }
 
 int sift3d_hip_describe_wlut2(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
                               uint32_t n, float *d_hist, float *d_hist2, float *d_wlut, void *stream)
 {
-    if (!n)
-        return SIFT3D_SUCCESS;
-    if (!d_wlut || nlevels < 1)
-        return describe_launch(d_levels, d_kp, n, d_hist, d_hist2, nullptr, stream);
-    hipLaunchKernelGGL(k_desc_wlut, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, d_levels, nlevels,
-                       d_wlut);
-    return describe_launch(d_levels, d_kp, n, d_hist, d_hist2, d_wlut, stream);
+    return sift3d_hip_describe_ex(d_levels, nlevels, d_kp, n, 0, d_hist, d_hist2, d_wlut, stream);
 }
 
 int sift3d_hip_describe_wlut(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,

@@ -133,6 +133,7 @@ struct _sift3d_detector {
     float *d_scalars;      /* [0] input max, [1] count (as u32), [8 + o*ndl + s] dogmax, then
                             * [8 + (num_octaves + o)*ndl + s] their lower bounds (sift3d_hip_dogmax_sub) */
     int t_pending;         /* stage events not yet read into t[]: 1 detect, 2 describe */
+    int exact_desc;        /* sift3d_amd_detector_set_exact_descriptors: 0 auto, 1 always, -1 never */
     int im_valid;          /* d_im holds the scaled image of the last detect call (else: see last_vol) */
     const float *last_vol; /* the last detect call's volume on the device (the caller's, or d_in) */
     int est0;              /* the large octaves' maxima gathered by their extrema sweeps (default; 0: a pass
@@ -1075,6 +1076,36 @@ int sift3d_amd_detector_set_dogmax_pass(sift3d_detector *d, int on)
     return SIFT3D_SUCCESS;
 }
 
+int sift3d_amd_detector_set_exact_descriptors(sift3d_detector *d, int mode)
+{
+    if (!d || mode < -1 || mode > 1)
+        return SIFT3D_FAILURE;
+    d->exact_desc = mode;
+    return SIFT3D_SUCCESS;
+}
+
+/* First level-in-octave index (s + 1, Gaussian index) whose keypoints take the reference-order descriptor
+ * kernel (sift3d_hip_describe_ex); ngl when none does.  A window of level s holds ~ (2 * half)^3 /
+ * (ux uy uz) voxels with half = 2 * sd * 7.071 / sqrt(2) (sift.c:1453-1456) and sd / units the same in
+ * every octave (Q9); a bin receives 1/32 of them.  Measured: 5e-6 maximal relative difference to the
+ * reference over 3.3e7 bins at 1.3e5 window voxels (512^3 fixture, fast commit); the difference grows
+ * with the square root of the terms per bin: 1.9e5 voxels keep it at ~6e-6, inside the 1e-5 bar. */
+static int exact_desc_first_level(int mode, int ngl, int K, double sigma0, const double *units)
+{
+    int lv;
+    if (mode > 0)
+        return 0;
+    if (mode < 0)
+        return ngl;
+    for (lv = 0; lv < ngl; lv++) {
+        const double sd = sigma0 * pow(2.0, (double)(lv - 1) / K);
+        const double side = 2.0 * (2.0 * sd * 7.071067812 / 1.4142135623730951);
+        if (side * side * side / (units[0] * units[1] * units[2]) > 1.9e5)
+            return lv;
+    }
+    return ngl;
+}
+
 int sift3d_detector_set_corner_thresh(sift3d_detector *const d, const double v)
 {
     if (v < 0.0 || v > 1.0) {                        /* sift.c:515-519 */
@@ -1820,7 +1851,8 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
 {
     const int num = (int)kp->num;
     const double t_start = now_s();
-    int i, lvbad = 0;
+    int i, lvbad = 0, lv_exact = 0;
+    size_t n_exact = 0;
 
     /* verify_keys, sift.c:1171-1212 (against the retained image dimensions) */
     if (num < 1) {
@@ -1893,6 +1925,7 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
             return SIFT3D_FAILURE;
         }
         memset(cnt, 0, sizeof(cnt));
+        lv_exact = exact_desc_first_level(d->exact_desc, d->ngl, d->num_kp_levels, d->sigma0, d->units);
 #pragma omp parallel num_threads(nt)
         {
             const int nth = omp_get_num_threads(), t = omp_get_thread_num();  /* (nth <= nt: see above) */
@@ -1905,11 +1938,16 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
             {
                 size_t pos = 0;
                 int lv, u;
-                for (lv = nlv - 1; lv >= 0; lv--)
+                for (lv = nlv - 1; lv >= 0; lv--) {
+                    if (lv == lv_exact - 1)
+                        n_exact = pos;         /* (widest windows first: the exact ones lead the list) */
                     for (u = 0; u < nth; u++) {
                         start[u][lv] = pos;
                         pos += cnt[u][lv];
                     }
+                }
+                if (lv_exact <= 0)
+                    n_exact = pos;
             }
             /* (implicit barrier) */
             for (q = lo; q < hi; q++) {
@@ -1966,10 +2004,9 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
         float *dev_view = (float *)sift3d_hip_host_device_ptr(desc->hist);
         const sift3d_hip_kp *kp_view = (const sift3d_hip_kp *)sift3d_hip_host_device_ptr(d->h_kp);
         if (!dev_view || !kp_view ||
-            sift3d_hip_describe_wlut2(d->d_levels, d->num_octaves * d->ngl, kp_view,
-                                                   (uint32_t)num, dev_view,
-                                                   desc->keep_device ? desc->d_hist : NULL, d->d_wlut,
-                                                   d->stream))
+            sift3d_hip_describe_ex(d->d_levels, d->num_octaves * d->ngl, kp_view, (uint32_t)num,
+                                   (uint32_t)n_exact, dev_view, desc->keep_device ? desc->d_hist : NULL,
+                                   d->d_wlut, d->stream))
             return SIFT3D_FAILURE;
     }
     sift3d_hip_event_record(d->ev[7], d->stream);

@@ -572,6 +572,156 @@ __global__ __launch_bounds__(256) void k_fir_x_u1(FirParams P, FirTaps T, EdgeTa
     }
 }
 
+// The same pass for rows of whole 512-float segments (nx % 512 == 0, 16-byte aligned: every volume of the
+// BASELINE configurations), with TWO rows in flight per wave.  k_fir_x_u1 above is bound by latency x
+// occupancy, not by bytes (measured: 0.228-0.236 ms at 6 waves per SIMD, 0.275-0.280 ms at 5, for the same
+// 8 B/voxel; one row = 2 KB in flight per wave): here the loads of rows r + 1 AND r + 2 fly while row r is
+// filtered.  All vector-memory instructions of the loop body are issued unconditionally (clamped addresses,
+// values masked when they are committed to LDS; the tail re-requests the last row), so the body is
+// straight-line code and the compiler's s_waitcnt vmcnt counts are exact -- a load or store behind a
+// lane- or wave-dependent branch would make it wait for the younger row as well.
+constexpr int XROWS_F = 8;
+
+template <int HW, bool SCALED>
+__global__ __launch_bounds__(256) void k_fir_x_u1f(FirParams P, FirTaps T, EdgeTab E)
+{
+    constexpr int SEG = 512, HALO = 8, L = SEG + 2 * HALO;
+    static_assert(HW <= HALO, "halo too small");
+    __shared__ __attribute__((aligned(16))) float lds[4][2][L];
+    // where the lanes that have no third quad / no edge sample to commit put theirs: every commit is then
+    // free of branches, and no load is left "maybe consumed" at the loop's back edge
+    __shared__ __attribute__((aligned(16))) float lds_sink[4][64 * 4];
+    // (wave-uniform by construction; said so, or the row loop's exits become lane-divergent control flow)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int nrows = P.ny * (P.z_hi - P.z_lo);
+    // (back to front, as k_fir_x_u1: the producer of `src` ended at the last planes)
+    const int row0 = ((gridDim.y - 1 - blockIdx.y) * 4 + wave) * XROWS_F;
+    if (row0 >= nrows)
+        return;
+    const int nr = min(XROWS_F, nrows - row0);
+    const int x0 = blockIdx.x * SEG;
+    const int nx = P.nx, end = nx - 1;
+    const size_t base = (size_t)P.z_lo * P.ny * nx;
+    // quads of the extended segment this lane stages: i = lane, lane + 64, lane + 128 (< L / 4 = 132)
+    const int g0 = x0 - HALO + 4 * lane, g1 = g0 + 256, g2 = g0 + 512;
+    const bool in0 = g0 >= 0, use2 = lane < 4, in2 = use2 && g2 + 3 < nx;
+    const int c0 = in0 ? g0 : 0, c2 = in2 ? g2 : nx - 4;
+    // edge samples of the extended line, one per lane (ext_sample's cases)
+    const int egi = lane < 8 ? -1 - lane : end + (lane - 8);
+    const int epos = egi - (x0 - HALO);
+    const bool has_edge = lane < 17 && epos >= 0 && epos < L;
+    int eo0 = 0, eo1 = 0;
+    float ew0 = 0.0f, ew1 = 0.0f;                 // (beyond the taps' reach: 0)
+    if (lane < 17) {
+        if (egi < 0) {
+            if (-egi <= HW) {
+                eo0 = clampi(-egi, 0, nx - 1);
+                ew0 = 1.0f;
+            }
+        } else if (egi - end <= HW) {
+            // (selects, not E.lo[m]: a lane-dependent index into a kernel argument would go through scratch)
+            const int m = egi - end;
+            int lo = 0;
+#pragma unroll
+            for (int mm = 0; mm <= HW; mm++)
+                if (mm == m) {
+                    lo = E.lo[mm];
+                    ew0 = E.w0[mm];
+                    ew1 = E.w1[mm];
+                }
+            eo0 = clampi(lo, 0, nx - 1);
+            eo1 = clampi(lo + 1, 0, nx - 1);
+        }
+    }
+    const bool edge_lerp = egi >= end;
+    // SCALED: im_scale folded in (imutil.c:698-713); a maximum of 0 leaves the image alone (imutil.c:706-707):
+    // every sample is then 0 and 0 / 1 = 0 exactly
+    float smax = 1.0f;
+    if (SCALED) {
+        smax = *P.scale_max;
+        smax = smax != 0.0f ? smax : 1.0f;
+    }
+
+    struct RowRegs {
+        float4 v0, v1, v2;
+        float e0, e1;
+    };
+    auto fetch = [&](RowRegs &R, int r) {
+        const float *__restrict__ s = P.src + base + (size_t)(row0 + min(r, nr - 1)) * nx;
+        R.v0 = ld4(s + c0);
+        R.v1 = ld4(s + g1);
+        R.v2 = ld4(s + c2);
+        R.e0 = s[eo0];
+        R.e1 = s[eo1];
+    };
+    auto commit = [&](const RowRegs &R, int buf) {
+        float4 q0 = R.v0, q1 = R.v1, q2 = R.v2;
+        float a = R.e0, b = R.e1;
+        if (SCALED) {                                           // imutil.c:711, formed when committed
+            q0.x = q0.x / smax; q0.y = q0.y / smax; q0.z = q0.z / smax; q0.w = q0.w / smax;
+            q1.x = q1.x / smax; q1.y = q1.y / smax; q1.z = q1.z / smax; q1.w = q1.w / smax;
+            q2.x = q2.x / smax; q2.y = q2.y / smax; q2.z = q2.z / smax; q2.w = q2.w / smax;
+            a = a / smax;
+            b = b / smax;
+        }
+        // (component selects: a select between two float4 objects would go through scratch)
+        q0.x = in0 ? q0.x : 0.0f; q0.y = in0 ? q0.y : 0.0f; q0.z = in0 ? q0.z : 0.0f; q0.w = in0 ? q0.w : 0.0f;
+        q2.x = in2 ? q2.x : 0.0f; q2.y = in2 ? q2.y : 0.0f; q2.z = in2 ? q2.z : 0.0f; q2.w = in2 ? q2.w : 0.0f;
+        float *const row = lds[wave][buf], *const sink = &lds_sink[wave][4 * lane];
+        *reinterpret_cast<float4 *>(row + 4 * lane) = q0;
+        *reinterpret_cast<float4 *>(row + 4 * (lane + 64)) = q1;
+        *reinterpret_cast<float4 *>(use2 ? row + 4 * (lane + 128) : sink) = q2;
+        // DS writes of a wave retire in order: the edge samples overwrite the bulk values
+        *(has_edge ? row + epos : sink) = edge_lerp ? ew0 * a + ew1 * b : (ew0 != 0.0f ? a : 0.0f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto compute = [&](int r, int buf) {
+        float *__restrict__ d = P.dst + base + (size_t)(row0 + r) * nx;
+#pragma unroll
+        for (int grp = 0; grp < 2; grp++) {
+            const int lb = grp * 256 + lane * 4;   // first output of this lane in the segment
+            float w[4 + 2 * HALO];
+#pragma unroll
+            for (int i = 0; i < (4 + 2 * HALO) / 4; i++) {
+                const float4 q = *reinterpret_cast<const float4 *>(&lds[wave][buf][lb + 4 * i]);
+                w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+            }
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int dd = -HW; dd <= HW; dd++)
+                    acc += T.k[dd + HW] * w[HALO + k - dd];   // E[x - d], d ascending
+                o[k] = acc;
+            }
+            st4(d + x0 + lb, make_float4(o[0], o[1], o[2], o[3]));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    RowRegs A, B;
+    fetch(A, 0);
+    fetch(B, 1);
+    commit(A, 0);
+    // (every commit on the straight path to the back edge: a commit under its own condition would leave the
+    // loop header with loads the compiler must assume unwaited, and it would wait for row r + 1 there)
+    for (int r = 0;; r += 2) {
+        fetch(A, r + 2);                      // rows r + 1 (B) and r + 2 (A) in flight during the FIR below
+        compute(r, 0);
+        if (r + 1 >= nr)
+            break;
+        commit(B, 1);
+        fetch(B, r + 3);
+        compute(r + 1, 1);
+        if (r + 2 >= nr)
+            break;
+        commit(A, 0);
+    }
+}
+
 // ---- y / z pass, unit factor 1 ----------------------------------------------------------
 // Each thread owns V adjacent x (one 16-byte quad for V=4) and sweeps `ts` outputs along
 // the strided axis, keeping the 2*HW+1 most recent rows of the EXTENDED line in a register
@@ -2635,6 +2785,15 @@ template <int HW>
 static void launch_fir_x_u1(const FirParams &P, const FirTaps &T, const EdgeTab &E, hipStream_t st)
 {
     const int nrows = P.ny * (P.z_hi - P.z_lo);
+    if ((P.nx & 511) == 0 && ((((uintptr_t)P.src | (uintptr_t)P.dst) & 15) == 0)) {
+        // rows of whole segments: two rows in flight per wave
+        dim3 grid(P.nx / 512, (nrows + 4 * XROWS_F - 1) / (4 * XROWS_F));
+        if (P.scale_max)
+            hipLaunchKernelGGL((k_fir_x_u1f<HW, true>), grid, dim3(256), 0, st, P, T, E);
+        else
+            hipLaunchKernelGGL((k_fir_x_u1f<HW, false>), grid, dim3(256), 0, st, P, T, E);
+        return;
+    }
     dim3 grid((P.nx + 511) / 512, (nrows + 4 * XROWS - 1) / (4 * XROWS));
     hipLaunchKernelGGL(k_fir_x_u1<HW>, grid, dim3(256), 0, st, P, T, E);
 }

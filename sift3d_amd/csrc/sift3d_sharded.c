@@ -67,6 +67,7 @@ struct sift3d_amd_sharded {
     int bounds[SH_MAX_OCT][SH_MAX_WORLD + 1];
     int K, ngl, ndl;                 /* keypoint / Gaussian / DoG levels per octave */
     int cuboid;
+    int exact_desc;                  /* sift3d_amd_detector_set_exact_descriptors of `params` */
     int dog_free[SH_MAX_OCT];        /* octave takes the DoG-free sweep (no stored DoG levels) */
     int win_reach[SH_MAX_NGL];
     filter_t filt[SH_MAX_NGL];
@@ -248,6 +249,7 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
     S->ngl = S->K + 3;                                             /* sift.c:434-437 */
     S->ndl = S->K + 2;
     S->cuboid = params ? params->cuboid_extrema : 0;
+    S->exact_desc = params ? params->exact_desc : 0;
     S->T = *T;
     S->rank = T->rank; S->world = T->world;
     S->peak_thresh = params ? params->peak_thresh : peak_thresh_default;
@@ -1115,6 +1117,7 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
 {
     const double t_start = now_s();
     int n = 0, num;
+    size_t n_exact = 0;
     if (!S || !kp || !desc || !own_idx || !n_own)
         return SIFT3D_FAILURE;
     num = (int)kp->num;
@@ -1197,6 +1200,9 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
     {
         enum { LVM = 16 };
         const int nt = host_threads((size_t)n);
+        /* (Gaussian index of the first level that takes the reference-order kernel; keypoint level s has
+         * Gaussian index s + 1) */
+        const int s_exact = exact_desc_first_level(S->exact_desc, S->ngl, S->K, S->sigma0, S->units) - 1;
         size_t cnt[HOST_THREADS_MAX][LVM], start[HOST_THREADS_MAX][LVM];
         if (S->K > LVM)
             return SIFT3D_FAILURE;
@@ -1213,11 +1219,16 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
             {
                 size_t p = 0;
                 int lv, u;
-                for (lv = S->K - 1; lv >= 0; lv--)
+                for (lv = S->K - 1; lv >= 0; lv--) {
+                    if (lv == s_exact - 1)
+                        n_exact = p;           /* (widest windows first: the exact ones lead the list) */
                     for (u = 0; u < nth; u++) {
                         start[u][lv] = p;
                         p += cnt[u][lv];
                     }
+                }
+                if (s_exact <= 0)
+                    n_exact = p;
             }
             /* (implicit barrier) */
             for (q = lo; q < hi; q++) {
@@ -1241,8 +1252,8 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
         float *dev_view = (float *)sift3d_hip_host_device_ptr(desc->hist);
         const sift3d_hip_kp *kp_view = (const sift3d_hip_kp *)sift3d_hip_host_device_ptr(S->h_kp);
         if (!dev_view || !kp_view ||
-            sift3d_hip_describe_wlut(S->d_levels, S->num_octaves * S->ngl, kp_view, (uint32_t)n, dev_view,
-                                     S->d_wlut, S->stream) ||
+            sift3d_hip_describe_ex(S->d_levels, S->num_octaves * S->ngl, kp_view, (uint32_t)n,
+                                   (uint32_t)n_exact, dev_view, NULL, S->d_wlut, S->stream) ||
             sift3d_hip_stream_sync(S->stream))
             return SIFT3D_FAILURE;
     }

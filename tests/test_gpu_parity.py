@@ -301,6 +301,17 @@ def test_detect_describe_golden(gpu, oracle_mod, name):
     np.testing.assert_allclose(m[:, 3:].astype(np.float64).sum(1), g["desc_rowsum"], rtol=1e-5)
     # R: in practice bit-exact (reference-order sums)
     assert np.mean(k["R"] == g["kp_R"]) > 0.999
+    # the reference-order descriptor kernel (sift3d_amd_detector_set_exact_descriptors(1)): every histogram
+    # the reference's BIT FOR BIT -- the fixtures' sampled rows in full, all rows by their projections
+    assert det.set_exact_descriptors(1) == 0
+    desc2 = api.DescriptorStore()
+    assert det.extract_descriptors(kp, desc2) == 0
+    m2 = desc2.to_mat_rm()
+    np.testing.assert_array_equal(m2[idx, 3:] + np.float32(0), g["desc_hist"] + np.float32(0))
+    assert util.assert_desc_projection(m2[:, 3:], g["desc_proj"], rtol=1e-12) < 1e-12
+    if name in ("g3_sigma3", "g3_sigma5"):
+        # windows of 2e5 .. 4e6 voxels: the automatic mode has taken the reference-order kernel for them
+        np.testing.assert_array_equal(m, m2)
     for lim in (0, 10):
         det2, kp2, rc = _run_api(api, vol, tuple(g["units"]), params)
         kp2.sort_by_strength(lim)
@@ -471,6 +482,12 @@ def test_g5_512_golden(gpu, oracle_mod):
     assert exact_R, "R differs from the reference at 512^3"
     print("g5_512: max elementwise relative descriptor error on the sampled rows: %.3g"
           % util.rel_err(m[idx, 3:], g["desc_hist_s"]))
+    # the reference-order kernel: the digest of ALL 42 501 x 768 histogram values is the reference's
+    assert det.set_exact_descriptors(1) == 0
+    assert det.extract_descriptors(kp, desc) == 0
+    assert util.digest(desc.to_mat_rm()[:, 3:]) == dig["desc_hist"]
+    print("g5_512: reference-order descriptors: %.1f ms (fast commit: see the bench line)"
+          % (1e3 * det.timings()["describe"]))
 
 
 def test_read_image_then_detect(gpu, oracle_mod, tmp_path):
