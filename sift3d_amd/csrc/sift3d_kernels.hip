@@ -633,7 +633,6 @@ __global__ __launch_bounds__(256) void k_fir_x_u1f(FirParams P, FirTaps T, EdgeT
             eo1 = clampi(lo + 1, 0, nx - 1);
         }
     }
-    const bool edge_lerp = egi >= end;
     // SCALED: im_scale folded in (imutil.c:698-713); a maximum of 0 leaves the image alone (imutil.c:706-707):
     // every sample is then 0 and 0 / 1 = 0 exactly
     float smax = 1.0f;
@@ -672,7 +671,10 @@ __global__ __launch_bounds__(256) void k_fir_x_u1f(FirParams P, FirTaps T, EdgeT
         *reinterpret_cast<float4 *>(row + 4 * (lane + 64)) = q1;
         *reinterpret_cast<float4 *>(use2 ? row + 4 * (lane + 128) : sink) = q2;
         // DS writes of a wave retire in order: the edge samples overwrite the bulk values
-        *(has_edge ? row + epos : sink) = edge_lerp ? ew0 * a + ew1 * b : (ew0 != 0.0f ? a : 0.0f);
+        // (ext_sample's three cases in one expression, so that nothing here branches: a lone sample has
+        // weights (1, 0): 1 * a + 0 * b = a for finite data -- up to the sign of a zero, which no later
+        // comparison or non-zero sum can see --, a sample beyond the taps' reach (0, 0))
+        *(has_edge ? row + epos : sink) = ew0 * a + ew1 * b;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
     };
@@ -702,24 +704,32 @@ __global__ __launch_bounds__(256) void k_fir_x_u1f(FirParams P, FirTaps T, EdgeT
         __builtin_amdgcn_wave_barrier();
     };
 
-    RowRegs A, B;
-    fetch(A, 0);
-    fetch(B, 1);
-    commit(A, 0);
-    // (every commit on the straight path to the back edge: a commit under its own condition would leave the
-    // loop header with loads the compiler must assume unwaited, and it would wait for row r + 1 there)
-    for (int r = 0;; r += 2) {
-        fetch(A, r + 2);                      // rows r + 1 (B) and r + 2 (A) in flight during the FIR below
-        compute(r, 0);
-        if (r + 1 >= nr)
-            break;
-        commit(B, 1);
-        fetch(B, r + 3);
-        compute(r + 1, 1);
-        if (r + 2 >= nr)
-            break;
+    // The rows of this wave.  Called with the constant XROWS_F (all but the volume's last rows) the loop is
+    // unrolled completely: one basic block, in which the compiler's vmcnt counts are exact (at a loop header
+    // it merges the states of the entry and the back edge and waits for the younger row too).
+    auto rows = [&](const int n) __attribute__((always_inline)) {
+        RowRegs A, B;
+        fetch(A, 0);
+        fetch(B, 1);
         commit(A, 0);
-    }
+#pragma unroll
+        for (int r = 0; r < XROWS_F; r += 2) {
+            fetch(A, r + 2);                  // rows r + 1 (B) and r + 2 (A) in flight during the FIR below
+            compute(r, 0);
+            if (r + 1 >= n)
+                break;
+            commit(B, 1);
+            fetch(B, r + 3);
+            compute(r + 1, 1);
+            if (r + 2 >= n)
+                break;
+            commit(A, 0);
+        }
+    };
+    if (nr == XROWS_F)
+        rows(XROWS_F);
+    else
+        rows(nr);
 }
 
 // ---- y / z pass, unit factor 1 ----------------------------------------------------------
