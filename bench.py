@@ -103,10 +103,13 @@ def kernel_microbench(torch, hip, n, reps=10):
         torch.cuda.synchronize()
         x_ms = [ev[3 * r].elapsed_time(ev[3 * r + 1]) for r in range(reps)]
         yz_ms = [ev[3 * r + 1].elapsed_time(ev[3 * r + 2]) for r in range(reps)]
-        row("k_fir_x_u1<%d>" % hw, hw, 0, 8.0, x_ms, True)
-        # (the launcher's tile choice, sift3d_fir_yz.hip: 64 x 64 on tall volumes, else 128 x 32 / 64 x 32)
-        tile = "64, 16" if (n % 64 == 0 and n >= 128) else ("32, 32" if n % 128 == 0 else "32, 16")
-        row("k_fir_yz_u1<%d, %s>" % (hw, tile), hw, 12, 16.0, yz_ms, True)   # two 1-D passes = 16 B/voxel
+        # (the launchers' choices: sift3d_kernels.hip launch_fir_x_u1, sift3d_fir_yz.hip launch_fir_yz)
+        row(("k_fir_x_u1f<%d, 0>" if n % 512 == 0 else "k_fir_x_u1<%d>") % hw, hw, 0, 8.0, x_ms, True)
+        if n % 64 == 0 and n >= 128:
+            yzname = "k_fir_yz_dma<%d, %d>" % (hw, 64 if hw <= 2 else 32)
+        else:
+            yzname = "k_fir_yz_u1<%d, %s>" % (hw, "32, 32" if n % 128 == 0 else "32, 16")
+        row(yzname, hw, 12, 16.0, yz_ms, True)   # two 1-D passes = 16 B/voxel
 
         def timed(fn):
             fn()
