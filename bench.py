@@ -346,7 +346,7 @@ def main():
     ap.add_argument("--no-host", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
     ap.add_argument("--rehearse-threads", type=int, default=0, metavar="R",
                     help="N=1 only: R slab drivers as R threads of this process on the one device "
-                         "(sharded_c.ThreadTransport) -- exercises the N = R code path and geometry where "
+                         "(sharded_c.StreamThreadTransport) -- exercises the N = R code path and geometry where "
                          "R processes may not share a card; the numbers are not a scaling measurement")
     ap.add_argument("--register", action="store_true",
                     help="BASELINE configs[4]: two volumes, detect+describe both, descriptor matching on "
@@ -395,7 +395,7 @@ def main():
         import threading
         from sift3d_amd import sharded_c
         nz_total = n if a.strong else n * rt
-        grp = sharded_c.ThreadGroup(rt)
+        grp = sharded_c.StreamThreadGroup(rt)      # stream-ordered exchanges (events only), as over RCCL
         jobs = [None] * rt
 
         def _threads(fn):
@@ -416,7 +416,7 @@ def main():
                 raise SystemExit("rehearsal failed: %s" % err)
 
         def _make(r):
-            jobs[r] = sharded_c.CShardedSift3D(n, n, nz_total, sharded_c.ThreadTransport(grp, r))
+            jobs[r] = sharded_c.CShardedSift3D(n, n, nz_total, sharded_c.StreamThreadTransport(grp, r))
             jobs[r].synth(seed=11)
         _threads(_make)
         step = lambda: _threads(lambda r: jobs[r].step())  # noqa: E731

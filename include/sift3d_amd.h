@@ -233,11 +233,12 @@ SIFT3D_AMD_API void sift3d_amd_thread_transport_free(sift3d_amd_transport *t);
  * buffer sift3d_amd_sharded_input() (x fastest, (z1 - z0) * ny * nx floats).  detect fills `kp`
  * with the GLOBAL keypoint list on every rank; describe computes the descriptors of the
  * keypoints this rank owns (their positions in `kp` go to own_idx, capacity kp's size).
- * Failures: detect / describe are collective.  A failure that every rank sees (bad arguments, a
- * transport error) returns SIFT3D_FAILURE everywhere; a rank-LOCAL failure between two collectives (out of
- * memory, a halo that does not fit the slab) returns SIFT3D_FAILURE on that rank only while the others
- * wait in the next collective -- the caller must then abort the communicator (as after any failed
- * collective), there is no in-band status exchange. */
+ * Failures: detect and the descriptor gather are collective.  A failure that every rank sees (bad arguments,
+ * a transport error, an exchange buffer that cannot be allocated) returns SIFT3D_FAILURE at once.  A rank whose
+ * LOCAL work fails (a launch, an allocation) keeps issuing every exchange of the step in the common order, its
+ * status word travels behind the blocks of both all-gathers, and EVERY rank returns SIFT3D_FAILURE at the same
+ * point with the transport in step for the next call (the reference: every stage returns -1 to its caller,
+ * immacros.h:27-32). */
 typedef struct sift3d_amd_sharded sift3d_amd_sharded;
 SIFT3D_AMD_API sift3d_amd_sharded *
 sift3d_amd_sharded_create(int nx, int ny, int nz, const sift3d_amd_transport *t,
@@ -250,6 +251,18 @@ SIFT3D_AMD_API int sift3d_amd_sharded_detect(sift3d_amd_sharded *, sift3d_keypoi
 SIFT3D_AMD_API int sift3d_amd_sharded_describe(sift3d_amd_sharded *, const sift3d_keypoint_store *kp,
                                                sift3d_descriptor_store *desc, int *own_idx,
                                                int *n_own);
+/* The descriptors of ALL keypoints of `kp`, in its (global) order, from the rows every rank computed
+ * (sift3d_amd_sharded_describe: desc_own / own_idx / n_own of THIS rank): one all-gather of the ranks' row
+ * blocks, device to device.  root < 0: `all` is filled on every rank; else on rank `root` only (the others
+ * take part in the exchange and leave `all` alone).  Collective; the status word behind every block makes a
+ * rank-local failure return SIFT3D_FAILURE on every rank. */
+SIFT3D_AMD_API int
+sift3d_amd_sharded_gather_descriptors(sift3d_amd_sharded *, const sift3d_keypoint_store *kp,
+                                      const sift3d_descriptor_store *desc_own, const int *own_idx, int n_own,
+                                      sift3d_descriptor_store *all, int root);
+/* test hook: the next detect (where = 1, 2, 3: before the pyramid, after the extrema, between the two
+ * all-gathers) or descriptor gather (4) of this rank fails LOCALLY; 0 clears */
+SIFT3D_AMD_API int sift3d_amd_sharded_inject_failure(sift3d_amd_sharded *, int where);
 SIFT3D_AMD_API int sift3d_amd_sharded_num_candidates(const sift3d_amd_sharded *);
 /* eight doubles of the last step: [0] Gaussian pyramid (device s, halo exchanges of the blurs inside)
  * [1] detect wall  [2] describe wall  [3] DoG maxima + extrema (device s, incl. the all-reduce)
@@ -277,6 +290,10 @@ SIFT3D_AMD_API int sift3d_hip_memcpy_d2d(void *d_dst, const void *d_src, size_t 
 SIFT3D_AMD_API int sift3d_hip_memcpy2d_d2h(void *h_dst, size_t dst_pitch, const void *d_src,
                                            size_t src_pitch, size_t width, size_t height, void *stream);
 SIFT3D_AMD_API int sift3d_hip_stream_wait_event(void *stream, void *ev);
+/* descriptor rows (768 floats) out of the ranks' gathered blocks into the global order: row g = row
+ * (d_map[g] & 0xffffff) of block (d_map[g] >> 24) */
+SIFT3D_AMD_API int sift3d_hip_rows_scatter(float *d_dst, const void *d_all, size_t blk_bytes,
+                                           const uint32_t *d_map, uint32_t n, void *stream);
 /* d_dst[i] = max over r of d_rows[r * n + i] (the reduction step of the thread transport's all-reduce) */
 SIFT3D_AMD_API int sift3d_hip_max_rows(float *d_dst, const float *d_rows, int nrows, int n, void *stream);
 SIFT3D_AMD_API int sift3d_hip_memset(void *d_dst, int byte, size_t bytes, void *stream);
@@ -338,6 +355,7 @@ sift3d_hip_fir(const sift3d_hip_fir_args *args, void *stream);
  * than x, tap spacing other than 1, more than 17 taps, the literal variant). */
 SIFT3D_AMD_API int
 sift3d_hip_fir_x_scaled(const sift3d_hip_fir_args *args, const float *d_max, void *stream);
+SIFT3D_AMD_API int sift3d_hip_fir_x_scaled_covers(const sift3d_hip_fir_args *args);   /* 1: covered */
 
 /* The y and z passes of one blur fused into one launch when both have tap spacing 1 (octave 0):
  * dst = FIR_z(FIR_y(src)), bit-identical to two sift3d_hip_fir calls, without the intermediate
@@ -528,6 +546,20 @@ sift3d_hip_describe_wlut2(const sift3d_hip_level *d_levels, int nlevels, const s
 SIFT3D_AMD_API int
 sift3d_hip_describe_ex(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp, uint32_t n,
                        uint32_t n_exact, float *d_hist, float *d_hist2, float *d_wlut, void *stream);
+
+/* Device stages of the slab driver's keypoint exchange (sift3d_slab.hip): per-(octave, level) counts of a
+ * rank's candidates; the rank's block of the all-gather (|DoG| of every candidate, then the kept candidates as
+ * 56-byte records {o, s, x, y, z (global), R[9]} in order); the global list built from the gathered blocks
+ * (64-byte records {.., strength, pad} behind a 64-byte header whose first int32 is the ranks' status). */
+SIFT3D_AMD_API int sift3d_hip_slab_count(const sift3d_hip_cand *d_cand, const int32_t *d_keep, uint32_t n,
+                                         int ngl, int K, int nkey, int32_t *d_cnt, void *stream);
+SIFT3D_AMD_API size_t sift3d_hip_slab_pack_scratch_bytes(uint32_t n);
+SIFT3D_AMD_API int sift3d_hip_slab_pack(const sift3d_hip_level *d_levels, const sift3d_hip_cand *d_cand,
+                                        const int32_t *d_keep, const float *d_R, uint32_t n, int ngl,
+                                        float *d_vals, void *d_recs, void *d_scratch, void *stream);
+SIFT3D_AMD_API int sift3d_hip_slab_build(const void *d_all, size_t blk_bytes, size_t roff, size_t toff,
+                                         int world, int nkey, const uint32_t *d_tab, uint32_t tot_k,
+                                         uint32_t tot_c, void *d_out, void *stream);
 
 /* Icosahedron face table for the descriptor kernel (init_geometry, sift.c:148-259;
  * per-face constants of cart2bary, sift.c:276-297).  20 records of

@@ -2953,13 +2953,22 @@ int sift3d_hip_fir(const sift3d_hip_fir_args *a, void *stream) { return fir_impl
 
 // The x pass of a unit-spaced blur on src / *d_max (im_scale, imutil.c:698-713, folded into the pass: the
 // scaled image is never stored).  1: not covered (the caller scales first, then calls sift3d_hip_fir).
+// (one predicate for the entry's own check and for callers that must know BEFORE they launch: the slab
+// driver's ranks have to agree on the path whatever happens to one of them)
+int sift3d_hip_fir_x_scaled_covers(const sift3d_hip_fir_args *a)
+{
+    if (!a)
+        return 0;
+    const int hw = a->width / 2;
+    return !(a->axis != 0 || a->variant == 1 || a->unit_factor != 1.0f || hw < 1 || hw > 8 ||
+             a->nx < 2 * hw + 2 || a->nx >= (1 << 22));
+}
+
 int sift3d_hip_fir_x_scaled(const sift3d_hip_fir_args *a, const float *d_max, void *stream)
 {
     if (!a || !d_max)
         return SIFT3D_FAILURE;
-    const int hw = a->width / 2;
-    if (a->axis != 0 || a->variant == 1 || a->unit_factor != 1.0f || hw < 1 || hw > 8 || a->nx < 2 * hw + 2 ||
-        a->nx >= (1 << 22))
+    if (!sift3d_hip_fir_x_scaled_covers(a))
         return 1;
     return fir_impl(a, d_max, stream);
 }

@@ -100,12 +100,17 @@ struct sift3d_amd_sharded {
     float *d_wlut;
     void *d_otab;          /* orientation window tables + candidate sums (sift3d_hip_orient_tab) */
     size_t otab_bytes;
-    sift3d_hip_cand *d_cand, *h_cand;
-    float *d_R, *h_R;
-    int32_t *d_keep, *h_keep;
+    sift3d_hip_cand *d_cand;
+    float *d_R;
+    int32_t *d_keep;
     uint32_t cand_cap;
-    void *d_xchg, *h_xchg;           /* all-gather staging (device + pinned host mirror) */
-    size_t xchg_bytes;
+    void *d_xchg, *h_xchg;           /* the ranks' gathered blocks (device); the final list (pinned host) */
+    size_t xchg_bytes, hxchg_cap;
+    void *d_cnt, *h_cnt, *d_tab, *h_tab, *d_out, *d_pack;   /* counts, segment tables, list, scan scratch */
+    size_t cnt_cap, hcnt_cap, tab_cap, htab_cap, out_cap, pack_cap;
+    void *d_gath;                    /* descriptor gather staging (sift3d_amd_sharded_gather_descriptors) */
+    size_t gath_cap;
+    int failed, inject;              /* local failure mark of the running call; test hook */
     sift3d_hip_kp *h_kp;
     uint32_t kp_cap;
     int ncand;
@@ -201,8 +206,10 @@ void sift3d_amd_sharded_free(sift3d_amd_sharded *S)
     sift3d_hip_free(S->d_cand);
     sift3d_hip_free(S->d_R); sift3d_hip_free(S->d_keep); sift3d_hip_free(S->d_xchg);
     sift3d_hip_free(S->d_wlut); sift3d_hip_free(S->d_otab);
-    sift3d_hip_host_free(S->h_cand); sift3d_hip_host_free(S->h_R); sift3d_hip_host_free(S->h_keep);
     sift3d_hip_host_free(S->h_xchg); sift3d_hip_host_free(S->h_kp);
+    sift3d_hip_free(S->d_cnt); sift3d_hip_free(S->d_tab); sift3d_hip_free(S->d_out); sift3d_hip_free(S->d_pack);
+    sift3d_hip_free(S->d_gath);
+    sift3d_hip_host_free(S->h_cnt); sift3d_hip_host_free(S->h_tab);
     sift3d_hip_event_destroy(S->ev_x); sift3d_hip_event_destroy(S->ev_halo);
     sift3d_hip_event_destroy(S->ev0); sift3d_hip_event_destroy(S->ev1);
     sift3d_hip_event_destroy(S->ev2); sift3d_hip_event_destroy(S->ev3); sift3d_hip_event_destroy(S->ev4);
@@ -482,12 +489,41 @@ static int sh_fir(sift3d_amd_sharded *S, const float *src, float *dst, int o, in
     return sift3d_hip_fir(&a, stream);
 }
 
+/* ---- failures between collectives ------------------------------------------------------------- */
+/* detect and describe are collective.  A rank whose LOCAL work fails (a launch, an allocation, an injected
+ * test failure) must not leave the others waiting in the next exchange: it marks itself failed, skips its
+ * remaining local work and still issues every exchange in the common order (with whatever its buffers hold);
+ * its status word travels behind the first all-gather of the step (the counts) and behind the second (the
+ * records), and EVERY rank returns SIFT3D_FAILURE at the same point, with the transport in step for the next
+ * call -- the reference's "every stage returns -1 to its caller" (immacros.h:27-32), across ranks.  A
+ * failure of the transport itself is everybody's by nature and returns at once. */
+#define SH_DO(call)                                        \
+    do {                                                   \
+        if (!S->failed && (call))                          \
+            S->failed = __LINE__;                          \
+    } while (0)
+#define SH_COMM(call)                                      \
+    do {                                                   \
+        if (call)                                          \
+            return SIFT3D_FAILURE;                         \
+    } while (0)
+
+/* test hook: the next detect (where = 1: before the pyramid, 2: after the extrema, 3: between the two
+ * all-gathers) or describe-gather (4) of THIS rank fails locally */
+int sift3d_amd_sharded_inject_failure(sift3d_amd_sharded *S, int where)
+{
+    if (!S || where < 0 || where > 4)
+        return SIFT3D_FAILURE;
+    S->inject = where;
+    return SIFT3D_SUCCESS;
+}
+
 /* apply_Sep_FIR_filter (imutil.c:1127-1206) on a level: src -> dst (same geometry).  Sharded
  * octaves: x (and y) on the owned planes, halo exchange of the z pass's input overlapped with the
  * z pass of the interior planes. */
 /* d_scale_max (the first blur of the pyramid only, else NULL): the blur of src / *d_scale_max -- im_scale
  * folded into the x pass (sift3d_hip_fir_x_scaled); returns 2 without doing anything when that x pass does
- * not cover the configuration */
+ * not cover the configuration (the same answer on every rank) */
 static int sh_blur(sift3d_amd_sharded *S, const struct sh_chain *C, int o, const float *src, const sh_level *Lg,
                    float *dst, const filter_t *f, const float *d_scale_max)
 {
@@ -502,9 +538,10 @@ static int sh_blur(sift3d_amd_sharded *S, const struct sh_chain *C, int o, const
     const int reach = (int)ceilf((float)hw * ufz) + 1;
     const int exch = S->world > 1 && sh_sharded(S, o);
     float *zin;
-    int fused, ia, ib, rc;
+    int fused, ia, ib;
     if (d_scale_max) {
         sift3d_hip_fir_args fa;
+        int rc;
         memset(&fa, 0, sizeof(fa));
         fa.src = src; fa.dst = C->tmp_a;
         fa.nx = nx; fa.ny = ny; fa.nz = Lg->nloc;
@@ -512,18 +549,18 @@ static int sh_blur(sift3d_amd_sharded *S, const struct sh_chain *C, int o, const
         fa.unit_factor = ufx;
         fa.n_glob = nzo; fa.off = 0;
         fa.z_lo = a; fa.z_hi = b;
-        rc = sift3d_hip_fir_x_scaled(&fa, d_scale_max, C->stream);
+        /* (whether this x pass covers the configuration does not depend on the rank) */
+        rc = sift3d_hip_fir_x_scaled_covers(&fa) ? 0 : 1;
         if (rc == 1)
             return 2;
-        if (rc != SIFT3D_SUCCESS)
-            return SIFT3D_FAILURE;
-    } else if (sh_fir(S, src, C->tmp_a, o, Lg->nloc, 0, f, ufx, 0, a, b, C->stream))
-        return SIFT3D_FAILURE;
+        SH_DO(sift3d_hip_fir_x_scaled(&fa, d_scale_max, C->stream) != SIFT3D_SUCCESS);
+    } else {
+        SH_DO(sh_fir(S, src, C->tmp_a, o, Lg->nloc, 0, f, ufx, 0, a, b, C->stream));
+    }
     fused = ufy == 1.0f && ufz == 1.0f && sift3d_hip_fir_yz_u1_covers(C->tmp_a, dst, nx, ny, f->width, nzo);
     zin = C->tmp_a;
     if (!fused) {
-        if (sh_fir(S, C->tmp_a, C->tmp_b, o, Lg->nloc, 1, f, ufy, 0, a, b, C->stream))
-            return SIFT3D_FAILURE;
+        SH_DO(sh_fir(S, C->tmp_a, C->tmp_b, o, Lg->nloc, 1, f, ufy, 0, a, b, C->stream));
         zin = C->tmp_b;
     }
     /* interior planes need no halo: [ia, ib) */
@@ -532,28 +569,24 @@ static int sh_blur(sift3d_amd_sharded *S, const struct sh_chain *C, int o, const
     if (ib < ia)
         ia = ib = a;                                     /* thin slab: everything after the exchange */
     if (exch) {
-        if (sift3d_hip_event_record(C->ev_x, C->stream) ||
-            sift3d_hip_stream_wait_event(S->comm_stream, C->ev_x) ||
-            sh_halo(S, zin, Lg, plane, reach, S->comm_stream) ||
-            sift3d_hip_event_record(C->ev_halo, S->comm_stream))
-            return SIFT3D_FAILURE;
+        SH_COMM(sift3d_hip_event_record(C->ev_x, C->stream) ||
+                sift3d_hip_stream_wait_event(S->comm_stream, C->ev_x) ||
+                sh_halo(S, zin, Lg, plane, reach, S->comm_stream) ||
+                sift3d_hip_event_record(C->ev_halo, S->comm_stream));
     }
 #define SH_ZPASS(lo_, hi_)                                                                           \
     do {                                                                                             \
         if ((hi_) > (lo_)) {                                                                         \
-            if (fused) {                                                                             \
-                rc = sift3d_hip_fir_yz_u1(zin, dst, nx, ny, Lg->nloc, f->taps, f->width, nzo,        \
-                                          Lg->off, (lo_), (hi_), C->stream);                         \
-                if (rc != SIFT3D_SUCCESS)                                                            \
-                    return SIFT3D_FAILURE;                                                           \
-            } else if (sh_fir(S, zin, dst, o, Lg->nloc, 2, f, ufz, Lg->off, (lo_), (hi_), C->stream)) \
-                return SIFT3D_FAILURE;                                                               \
+            if (fused)                                                                               \
+                SH_DO(sift3d_hip_fir_yz_u1(zin, dst, nx, ny, Lg->nloc, f->taps, f->width, nzo,       \
+                                           Lg->off, (lo_), (hi_), C->stream) != SIFT3D_SUCCESS);     \
+            else                                                                                     \
+                SH_DO(sh_fir(S, zin, dst, o, Lg->nloc, 2, f, ufz, Lg->off, (lo_), (hi_), C->stream)); \
         }                                                                                            \
     } while (0)
     SH_ZPASS(ia, ib);
     if (exch) {
-        if (sift3d_hip_stream_wait_event(C->stream, C->ev_halo))
-            return SIFT3D_FAILURE;
+        SH_COMM(sift3d_hip_stream_wait_event(C->stream, C->ev_halo));
         SH_ZPASS(a, ia);
         SH_ZPASS(ib, b);
     }
@@ -561,36 +594,37 @@ static int sh_blur(sift3d_amd_sharded *S, const struct sh_chain *C, int o, const
     return SIFT3D_SUCCESS;
 }
 
-/* all-gather of `bytes` host bytes per rank through the device staging buffer; result (world *
- * bytes, rank order) in S->h_xchg */
-static int sh_allgather_host(sift3d_amd_sharded *S, const void *mine, size_t bytes)
+/* a device buffer of at least `bytes` (grown with a quarter of slack) */
+static int sh_ensure_dev(void **p, size_t *cap, size_t bytes)
 {
-    const size_t pad = (bytes + 15) & ~(size_t)15;
-    const size_t need = pad * (size_t)(S->world + 1);
-    if (need > S->xchg_bytes) {
-        sift3d_hip_free(S->d_xchg);
-        sift3d_hip_host_free(S->h_xchg);
-        S->xchg_bytes = 0;
-        S->d_xchg = sift3d_hip_malloc(need + need / 4);
-        S->h_xchg = sift3d_hip_host_alloc(need + need / 4);
-        if (!S->d_xchg || !S->h_xchg)
-            return SIFT3D_FAILURE;
-        S->xchg_bytes = need + need / 4;
-    }
-    if (S->world == 1) {
-        memcpy(S->h_xchg, mine, bytes);
+    if (bytes <= *cap)
         return SIFT3D_SUCCESS;
-    }
-    /* layout: [world * pad] gathered, then [pad] my contribution */
-    memset((char *)S->h_xchg + pad * S->world, 0, pad);
-    memcpy((char *)S->h_xchg + pad * S->world, mine, bytes);
-    if (sift3d_hip_memcpy_h2d((char *)S->d_xchg + pad * S->world, (char *)S->h_xchg + pad * S->world, pad,
-                              S->stream) ||
-        S->T.allgather(S->T.ctx, (char *)S->d_xchg + pad * S->world, S->d_xchg, pad, S->stream) ||
-        sift3d_hip_memcpy_d2h(S->h_xchg, S->d_xchg, pad * S->world, S->stream) ||
-        sift3d_hip_stream_sync(S->stream))
+    sift3d_hip_free(*p);
+    *cap = 0;
+    if (!(*p = sift3d_hip_malloc(bytes + bytes / 4)))
         return SIFT3D_FAILURE;
+    *cap = bytes + bytes / 4;
     return SIFT3D_SUCCESS;
+}
+
+static int sh_ensure_pinned(void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap)
+        return SIFT3D_SUCCESS;
+    sift3d_hip_host_free(*p);
+    *cap = 0;
+    if (!(*p = sift3d_hip_host_alloc(bytes + bytes / 4)))
+        return SIFT3D_FAILURE;
+    *cap = bytes + bytes / 4;
+    return SIFT3D_SUCCESS;
+}
+
+/* all-gather of one device block per rank, on the main stream (one rank: a copy) */
+static int sh_allgather_dev(sift3d_amd_sharded *S, const void *d_mine, void *d_all, size_t bytes)
+{
+    if (S->world == 1)
+        return sift3d_hip_memcpy_d2d(d_all, d_mine, bytes, S->stream);
+    return S->T.allgather(S->T.ctx, d_mine, d_all, bytes, S->stream);
 }
 
 static int sh_ensure_cand(sift3d_amd_sharded *S, uint32_t cap)
@@ -598,21 +632,24 @@ static int sh_ensure_cand(sift3d_amd_sharded *S, uint32_t cap)
     if (cap <= S->cand_cap)
         return SIFT3D_SUCCESS;
     sift3d_hip_free(S->d_cand); sift3d_hip_free(S->d_R); sift3d_hip_free(S->d_keep);
-    sift3d_hip_host_free(S->h_cand); sift3d_hip_host_free(S->h_R); sift3d_hip_host_free(S->h_keep);
     S->cand_cap = 0;
     S->d_cand = (sift3d_hip_cand *)sift3d_hip_malloc(sizeof(sift3d_hip_cand) * (size_t)cap);
     S->d_R = (float *)sift3d_hip_malloc(sizeof(float) * 9 * (size_t)cap);
     S->d_keep = (int32_t *)sift3d_hip_malloc(sizeof(int32_t) * (size_t)cap);
-    S->h_cand = (sift3d_hip_cand *)sift3d_hip_host_alloc(sizeof(sift3d_hip_cand) * (size_t)cap);
-    S->h_R = (float *)sift3d_hip_host_alloc(sizeof(float) * 9 * (size_t)cap);
-    S->h_keep = (int32_t *)sift3d_hip_host_alloc(sizeof(int32_t) * (size_t)cap);
-    if (!S->d_cand || !S->d_R || !S->d_keep || !S->h_cand || !S->h_R || !S->h_keep)
+    if (!S->d_cand || !S->d_R || !S->d_keep)
         return SIFT3D_FAILURE;
     S->cand_cap = cap;
     return SIFT3D_SUCCESS;
 }
 
 /* ---- detect -------------------------------------------------------------------------------- */
+typedef struct {          /* a record of the global list as sift3d_hip_slab_build delivers it */
+    int32_t o, s, x, y, z;
+    float R[9];
+    float strength;
+    int32_t pad;
+} sh_out;
+
 int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
 {
     const double t_start = now_s();
@@ -621,21 +658,21 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
     if (!S || !kp)
         return SIFT3D_FAILURE;
     nkey = S->num_octaves * S->K;
+    if (nkey > 256)
+        return SIFT3D_FAILURE;
     for (o = 0; o < S->num_octaves; o++)
         all_free = all_free && S->dog_free[o];
+    S->failed = S->inject == 1 ? -1 : 0;
 
     /* set_im_SIFT3D: scale by the GLOBAL max|v| (sift.c:645-649) */
     sift3d_hip_event_record(S->ev4, S->stream);
     {
         const size_t n_in = sh_plane(S, 0) * (size_t)(S->in_z1 - S->in_z0);
-        const sh_level *L0 = &S->G[0][0];
-        const int a = sh_sharded(S, 0) ? L0->z0 - L0->off : 0;
-        if (sift3d_hip_memset(S->d_scalars, 0, sizeof(float) * (8 + SH_MAX_NDL * SH_MAX_OCT), S->stream) ||
-            sift3d_hip_absmax(S->d_raw, n_in, S->d_scalars, S->stream))
-            return SIFT3D_FAILURE;
-        if (S->world > 1 && S->T.allreduce_max(S->T.ctx, S->d_scalars, 1, S->stream))
-            return SIFT3D_FAILURE;
-        (void)a;        /* (im_scale itself: folded into the first blur below, or run there) */
+        SH_DO(sift3d_hip_memset(S->d_scalars, 0, sizeof(float) * (8 + SH_MAX_NDL * SH_MAX_OCT), S->stream) ||
+              sift3d_hip_absmax(S->d_raw, n_in, S->d_scalars, S->stream));
+        if (S->world > 1)
+            SH_COMM(S->T.allreduce_max(S->T.ctx, S->d_scalars, 1, S->stream));
+        /* (im_scale itself: folded into the first blur below, or run there) */
     }
     /* build_gpyr, sift.c:662-711 -- on three dependency chains, as the single-GPU path builds it
      * (detect_on_device): octave o + 1 starts from level K of octave o (sift.c:696-704) and the levels after
@@ -662,28 +699,24 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
                 int rc = sh_blur(S, C0, 0, S->d_raw - (size_t)a0 * sh_plane(S, 0), L0, L0->t, &S->filt[0],
                                  S->d_scalars);
                 if (rc == 2) {
-                    if (sift3d_hip_scale(S->d_raw, S->d_im + (size_t)a0 * sh_plane(S, 0), n_in, S->d_scalars,
-                                         S->stream) ||
-                        sh_blur(S, C0, 0, S->d_im, L0, L0->t, &S->filt[0], NULL))
-                        return SIFT3D_FAILURE;
+                    SH_DO(sift3d_hip_scale(S->d_raw, S->d_im + (size_t)a0 * sh_plane(S, 0), n_in, S->d_scalars,
+                                           S->stream));
+                    SH_COMM(sh_blur(S, C0, 0, S->d_im, L0, L0->t, &S->filt[0], NULL));
                 } else if (rc != SIFT3D_SUCCESS) {
                     return SIFT3D_FAILURE;
                 }
             }
             for (s = 1; s <= S->K && s < S->ngl; s++)
-                if (sh_blur(S, Ca, o, S->G[o][s - 1].t, &S->G[o][s], S->G[o][s].t, &S->filt[s], NULL))
-                    return SIFT3D_FAILURE;
+                SH_COMM(sh_blur(S, Ca, o, S->G[o][s - 1].t, &S->G[o][s], S->G[o][s].t, &S->filt[s], NULL));
             if (forked) {
                 /* level K exists: the next octave (chain 1) and this octave's last levels (chain 2, or the
                  * main stream for octave 0) go their own ways */
-                if (o == 0) {
-                    if (sift3d_hip_event_record(S->ev_fork, S->stream) ||
-                        sift3d_hip_stream_wait_event(S->oct_stream, S->ev_fork))
-                        return SIFT3D_FAILURE;
-                } else if (sift3d_hip_event_record(S->ev_oct[o], Ca->stream) ||
-                           sift3d_hip_stream_wait_event(Cb->stream, S->ev_oct[o])) {
-                    return SIFT3D_FAILURE;
-                }
+                if (o == 0)
+                    SH_COMM(sift3d_hip_event_record(S->ev_fork, S->stream) ||
+                            sift3d_hip_stream_wait_event(S->oct_stream, S->ev_fork));
+                else
+                    SH_COMM(sift3d_hip_event_record(S->ev_oct[o], Ca->stream) ||
+                            sift3d_hip_stream_wait_event(Cb->stream, S->ev_oct[o]));
             }
             if (o != S->num_octaves - 1) {
                 /* level max(s_end - 2, first_level) = Gaussian index K, sift.c:696-704; on the stream that
@@ -709,49 +742,43 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
                         float *mine = S->d_stage, *all;
                         const size_t slab = (size_t)mxn * pl_d;
                         if (slab * (size_t)(S->world + 1) > S->stage_elems)
-                            return SIFT3D_FAILURE;
+                            return SIFT3D_FAILURE;       /* (geometry: the same on every rank) */
                         all = mine + slab;
-                        if (sift3d_hip_memset(mine, 0, slab * sizeof(float), ds))
-                            return SIFT3D_FAILURE;
-                        if (z1 > z0 && sift3d_hip_downsample2(src->t + (size_t)(2 * z0 - src->off) * pl_s,
-                                                              S->dims[o][0], S->dims[o][1], mine, mx, my,
-                                                              z1 - z0, ds))
-                            return SIFT3D_FAILURE;
+                        SH_DO(sift3d_hip_memset(mine, 0, slab * sizeof(float), ds));
+                        if (z1 > z0)
+                            SH_DO(sift3d_hip_downsample2(src->t + (size_t)(2 * z0 - src->off) * pl_s,
+                                                         S->dims[o][0], S->dims[o][1], mine, mx, my, z1 - z0, ds));
                         /* the collective on the main stream (behind what that stream holds), the next
                          * octave behind the collective */
-                        if (ds != S->stream && (sift3d_hip_event_record(S->ev_tr, ds) ||
-                                                sift3d_hip_stream_wait_event(S->stream, S->ev_tr)))
-                            return SIFT3D_FAILURE;
-                        if (S->T.allgather(S->T.ctx, mine, all, slab * sizeof(float), S->stream))
-                            return SIFT3D_FAILURE;
+                        if (ds != S->stream)
+                            SH_COMM(sift3d_hip_event_record(S->ev_tr, ds) ||
+                                    sift3d_hip_stream_wait_event(S->stream, S->ev_tr));
+                        SH_COMM(S->T.allgather(S->T.ctx, mine, all, slab * sizeof(float), S->stream));
                         for (r = 0; r < S->world; r++)
-                            if (zb[r + 1] > zb[r] &&
-                                sift3d_hip_memcpy_d2d(dst->t + (size_t)zb[r] * pl_d, all + (size_t)r * slab,
-                                                      (size_t)(zb[r + 1] - zb[r]) * pl_d * sizeof(float),
-                                                      S->stream))
-                                return SIFT3D_FAILURE;
-                        if (ds != S->stream && (sift3d_hip_event_record(S->ev_tr, S->stream) ||
-                                                sift3d_hip_stream_wait_event(ds, S->ev_tr)))
-                            return SIFT3D_FAILURE;
+                            if (zb[r + 1] > zb[r])
+                                SH_DO(sift3d_hip_memcpy_d2d(dst->t + (size_t)zb[r] * pl_d, all + (size_t)r * slab,
+                                                            (size_t)(zb[r + 1] - zb[r]) * pl_d * sizeof(float),
+                                                            S->stream));
+                        if (ds != S->stream)
+                            SH_COMM(sift3d_hip_event_record(S->ev_tr, S->stream) ||
+                                    sift3d_hip_stream_wait_event(ds, S->ev_tr));
                     }
                 } else {
                     const int z0 = sh_sharded(S, o + 1) ? dst->z0 : 0, z1 = sh_sharded(S, o + 1) ? dst->z1 : mzg;
-                    if (z1 > z0 && sift3d_hip_downsample2(src->t + (size_t)(2 * z0 - src->off) * pl_s,
-                                                          S->dims[o][0], S->dims[o][1],
-                                                          dst->t + (size_t)(z0 - dst->off) * pl_d, mx, my,
-                                                          z1 - z0, ds))
-                        return SIFT3D_FAILURE;
+                    if (z1 > z0)
+                        SH_DO(sift3d_hip_downsample2(src->t + (size_t)(2 * z0 - src->off) * pl_s, S->dims[o][0],
+                                                     S->dims[o][1], dst->t + (size_t)(z0 - dst->off) * pl_d, mx,
+                                                     my, z1 - z0, ds));
                 }
             }
             for (s = S->K + 1; s < S->ngl; s++)
-                if (sh_blur(S, Cb, o, S->G[o][s - 1].t, &S->G[o][s], S->G[o][s].t, &S->filt[s], NULL))
-                    return SIFT3D_FAILURE;
+                SH_COMM(sh_blur(S, Cb, o, S->G[o][s - 1].t, &S->G[o][s], S->G[o][s].t, &S->filt[s], NULL));
         }
-        if (forked && (sift3d_hip_event_record(S->ev_join, S->oct_stream) ||
-                       sift3d_hip_stream_wait_event(S->stream, S->ev_join) ||
-                       sift3d_hip_event_record(S->ev_join2, S->side_stream) ||
-                       sift3d_hip_stream_wait_event(S->stream, S->ev_join2)))
-            return SIFT3D_FAILURE;
+        if (forked)
+            SH_COMM(sift3d_hip_event_record(S->ev_join, S->oct_stream) ||
+                    sift3d_hip_stream_wait_event(S->stream, S->ev_join) ||
+                    sift3d_hip_event_record(S->ev_join2, S->side_stream) ||
+                    sift3d_hip_stream_wait_event(S->stream, S->ev_join2));
     }
     sift3d_hip_event_record(S->ev1, S->stream);
 
@@ -759,8 +786,7 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
      * past the slab, and stored DoG levels are formed on it */
     for (o = 0; o < S->o_shard; o++)
         for (s = 0; s < S->ngl; s++)
-            if (sh_halo_range(S, S->G[o][s].t, &S->G[o][s], sh_plane(S, o), 0, 1, S->stream))
-                return SIFT3D_FAILURE;
+            SH_COMM(sh_halo_range(S, S->G[o][s].t, &S->G[o][s], sh_plane(S, o), 0, 1, S->stream));
 
     /* dogmax (sift.c:821-826) of every octave on the owned planes (every plane is owned by some
      * rank), one all-reduce for all of them.  Octaves of the DoG-free sweep store no DoG level; the
@@ -775,67 +801,61 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
         if (S->dog_free[o]) {
             for (s = 0; s < S->ngl; s++)
                 g[s] = S->G[o][s].t + (size_t)lo * plane;
-            if (hi > lo && sift3d_hip_dogmax_stack(g, S->ngl, (size_t)(hi - lo) * plane,
-                                                   S->d_scalars + 8 + S->ndl * o, S->stream) != SIFT3D_SUCCESS)
-                return SIFT3D_FAILURE;
+            if (hi > lo)
+                SH_DO(sift3d_hip_dogmax_stack(g, S->ngl, (size_t)(hi - lo) * plane,
+                                              S->d_scalars + 8 + S->ndl * o, S->stream) != SIFT3D_SUCCESS);
         } else {
             const int lo2 = lo > 0 ? lo - 1 : 0, hi2 = hi < L->nloc ? hi + 1 : L->nloc;
             const size_t n2 = (size_t)(hi2 - lo2) * plane;
             float *dd[SH_MAX_NDL];
-            int rc;
+            int rc = 0;
             if (hi <= lo)
                 continue;
             for (s = 0; s < S->ngl; s++)
                 g[s] = S->G[o][s].t + (size_t)lo2 * plane;
             for (s = 0; s < S->ndl; s++)
                 dd[s] = S->D[o][s] + (size_t)lo2 * plane;
-            rc = sift3d_hip_dog_stack(g, dd, S->ngl, n2, S->d_scalars + 8 + S->ndl * o, S->stream);
+            if (!S->failed)
+                rc = sift3d_hip_dog_stack(g, dd, S->ngl, n2, S->d_scalars + 8 + S->ndl * o, S->stream);
             if (rc == 1) {
                 for (s = 0; s < S->ndl; s++)
-                    if (sift3d_hip_subtract_absmax(g[s], g[s + 1], dd[s], n2,
-                                                   S->d_scalars + 8 + S->ndl * o + s, S->stream))
-                        return SIFT3D_FAILURE;
+                    SH_DO(sift3d_hip_subtract_absmax(g[s], g[s + 1], dd[s], n2,
+                                                     S->d_scalars + 8 + S->ndl * o + s, S->stream));
             } else if (rc != SIFT3D_SUCCESS) {
-                return SIFT3D_FAILURE;
+                SH_DO(1);
             }
         }
     }
-    if (S->world > 1 &&
-        S->T.allreduce_max(S->T.ctx, S->d_scalars + 8, S->ndl * S->num_octaves, S->stream))
-        return SIFT3D_FAILURE;
+    if (S->world > 1)
+        SH_COMM(S->T.allreduce_max(S->T.ctx, S->d_scalars + 8, S->ndl * S->num_octaves, S->stream));
 
     /* The windows of the orientation and descriptor kernels reach win_reach[s] planes into the
      * neighbours' slabs: the largest exchange of a step.  It travels on the communication stream
      * WHILE the extrema are found, and is awaited before the orientation kernel.  (No collective is
      * issued on the compute stream in between: one communicator, one order.) */
     if (S->world > 1 && S->o_shard > 0) {
-        if (sift3d_hip_event_record(S->ev_x, S->stream) ||
-            sift3d_hip_stream_wait_event(S->comm_stream, S->ev_x))
-            return SIFT3D_FAILURE;
+        SH_COMM(sift3d_hip_event_record(S->ev_x, S->stream) ||
+                sift3d_hip_stream_wait_event(S->comm_stream, S->ev_x));
         for (o = 0; o < S->o_shard; o++)
             for (s = 0; s < S->ngl; s++)
-                if (sh_halo_range(S, S->G[o][s].t, &S->G[o][s], sh_plane(S, o), 1, S->win_reach[s],
-                                  S->comm_stream))
-                    return SIFT3D_FAILURE;
-        if (sift3d_hip_event_record(S->ev_halo, S->comm_stream))
-            return SIFT3D_FAILURE;
+                SH_COMM(sh_halo_range(S, S->G[o][s].t, &S->G[o][s], sh_plane(S, o), 1, S->win_reach[s],
+                                      S->comm_stream));
+        SH_COMM(sift3d_hip_event_record(S->ev_halo, S->comm_stream));
     }
 
     /* detect_extrema (sift.c:735-871) on the owned planes, assign_orientations (sift.c:1109-1167)
      * for the local candidates */
-    if (sh_ensure_cand(S, S->cand_cap ? S->cand_cap : (1u << 18)))
-        return SIFT3D_FAILURE;
-    for (attempt = 0; attempt < 2; attempt++) {
+    SH_DO(sh_ensure_cand(S, S->cand_cap ? S->cand_cap : (1u << 18)));
+    for (attempt = 0; attempt < 2 && !S->failed; attempt++) {
         /* with every octave on the DoG-free sweep: the sweeps of octaves >= 1 (short launches) beside
          * octave 0's on a second stream, then scan + emission in octave order
          * (sift3d_hip_extrema_gauss6_phase); otherwise octave by octave */
         const int side = all_free && S->num_octaves > 1 && S->d_work2 != NULL;
         int phase;
-        if (sift3d_hip_memset(S->d_scalars + 1, 0, sizeof(uint32_t), S->stream))
-            return SIFT3D_FAILURE;
-        if (side && (sift3d_hip_event_record(S->ev_fork, S->stream) ||
-                     sift3d_hip_stream_wait_event(S->oct_stream, S->ev_fork)))
-            return SIFT3D_FAILURE;
+        SH_DO(sift3d_hip_memset(S->d_scalars + 1, 0, sizeof(uint32_t), S->stream));
+        if (side)
+            SH_COMM(sift3d_hip_event_record(S->ev_fork, S->stream) ||
+                    sift3d_hip_stream_wait_event(S->oct_stream, S->ev_fork));
         for (phase = side ? 1 : 0; phase <= (side ? 2 : 0); phase++) {
             for (o = 0; o < S->num_octaves; o++) {
                 const sh_level *L = &S->G[o][0];
@@ -852,13 +872,12 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
                 if (L->nloc < 3 || zh <= zl)
                     continue;                            /* no interior plane on this rank */
                 if (S->dog_free[o]) {
-                    if (sift3d_hip_extrema_gauss6_phase(g, S->d_scalars + 8 + S->ndl * o, S->dims[o][0],
-                                                        S->dims[o][1], L->nloc, zl, zh, o * S->ngl + 1,
-                                                        S->peak_thresh, S->d_cand, S->cand_cap,
-                                                        (uint32_t *)(S->d_scalars + 1), wk, wb,
-                                                        phase == 1 && o > 0 ? S->oct_stream : S->stream,
-                                                        phase) != SIFT3D_SUCCESS)
-                        return SIFT3D_FAILURE;
+                    SH_DO(sift3d_hip_extrema_gauss6_phase(g, S->d_scalars + 8 + S->ndl * o, S->dims[o][0],
+                                                          S->dims[o][1], L->nloc, zl, zh, o * S->ngl + 1,
+                                                          S->peak_thresh, S->d_cand, S->cand_cap,
+                                                          (uint32_t *)(S->d_scalars + 1), wk, wb,
+                                                          phase == 1 && o > 0 ? S->oct_stream : S->stream,
+                                                          phase) != SIFT3D_SUCCESS);
                 } else {
                     sift3d_hip_extrema_level lv[SH_MAX_K];
                     for (s = 0; s < S->K; s++) {
@@ -870,27 +889,28 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
                         lv[s].z_hi = zh;
                         lv[s].tag = o * S->ngl + s + 1;          /* Gaussian level (o, s) of the table */
                     }
-                    if (sift3d_hip_extrema_mode(lv, S->K, S->dims[o][0], S->dims[o][1], L->nloc, S->peak_thresh,
-                                                S->cuboid, S->d_cand, S->cand_cap,
-                                                (uint32_t *)(S->d_scalars + 1), wk, wb, S->stream))
-                        return SIFT3D_FAILURE;
+                    SH_DO(sift3d_hip_extrema_mode(lv, S->K, S->dims[o][0], S->dims[o][1], L->nloc, S->peak_thresh,
+                                                  S->cuboid, S->d_cand, S->cand_cap,
+                                                  (uint32_t *)(S->d_scalars + 1), wk, wb, S->stream));
                 }
             }
-            if (phase == 1 && (sift3d_hip_event_record(S->ev_join, S->oct_stream) ||
-                               sift3d_hip_stream_wait_event(S->stream, S->ev_join)))
-                return SIFT3D_FAILURE;
+            if (phase == 1)
+                SH_COMM(sift3d_hip_event_record(S->ev_join, S->oct_stream) ||
+                        sift3d_hip_stream_wait_event(S->stream, S->ev_join));
         }
-        if (sift3d_hip_memcpy_d2h(&count, S->d_scalars + 1, sizeof(count), S->stream) ||
-            sift3d_hip_stream_sync(S->stream))
-            return SIFT3D_FAILURE;
-        if (count <= S->cand_cap)
+        SH_DO(sift3d_hip_memcpy_d2h(&count, S->d_scalars + 1, sizeof(count), S->stream));
+        SH_COMM(sift3d_hip_stream_sync(S->stream));
+        if (S->failed || count <= S->cand_cap)
             break;
-        if (sh_ensure_cand(S, count + count / 4 + 1024))
-            return SIFT3D_FAILURE;
+        SH_DO(sh_ensure_cand(S, count + count / 4 + 1024));
     }
+    if (S->inject == 2)
+        S->failed = -2;
+    if (S->failed)
+        count = 0;
     sift3d_hip_event_record(S->ev2, S->stream);
-    if (S->world > 1 && S->o_shard > 0 && sift3d_hip_stream_wait_event(S->stream, S->ev_halo))
-        return SIFT3D_FAILURE;                           /* the window halos have arrived */
+    if (S->world > 1 && S->o_shard > 0)
+        SH_COMM(sift3d_hip_stream_wait_event(S->stream, S->ev_halo));    /* the window halos have arrived */
     if (count) {
         const size_t need = sift3d_hip_orient_tab_bytes(S->num_octaves * S->ngl, S->cand_cap);
         if (need > S->otab_bytes) {
@@ -899,205 +919,137 @@ int sift3d_amd_sharded_detect(sift3d_amd_sharded *S, sift3d_keypoint_store *kp)
             S->d_otab = sift3d_hip_malloc(need);
             /* zeroed once: the tables carry a validity mark (they are kept between calls) */
             if (!S->d_otab || sift3d_hip_memset(S->d_otab, 0, need, S->stream))
-                return SIFT3D_FAILURE;
-            S->otab_bytes = need;
+                SH_DO(1);
+            else
+                S->otab_bytes = need;
         }
-        if (sift3d_hip_orient_tab(S->d_levels, S->num_octaves * S->ngl, S->d_cand, count, S->corner_thresh,
-                                  S->d_R, S->d_keep, S->d_otab, S->cand_cap, S->stream) ||
-            sift3d_hip_memcpy_d2h(S->h_cand, S->d_cand, sizeof(sift3d_hip_cand) * (size_t)count, S->stream) ||
-            sift3d_hip_memcpy_d2h(S->h_R, S->d_R, sizeof(float) * 9 * (size_t)count, S->stream) ||
-            sift3d_hip_memcpy_d2h(S->h_keep, S->d_keep, sizeof(int32_t) * (size_t)count, S->stream))
-            return SIFT3D_FAILURE;
+        SH_DO(sift3d_hip_orient_tab(S->d_levels, S->num_octaves * S->ngl, S->d_cand, count, S->corner_thresh,
+                                    S->d_R, S->d_keep, S->d_otab, S->cand_cap, S->stream));
+        if (S->failed)
+            count = 0;
     }
     sift3d_hip_event_record(S->ev3, S->stream);
-    if (sift3d_hip_stream_sync(S->stream))
-        return SIFT3D_FAILURE;
     S->t_gather0 = now_s();
 
-    /* Exchange (all-gather): per-(o,s) counts, the candidates' |DoG| values and the
-     * ORIENTED keypoints only.  Global order: (o, s) major, then ranks in slab order (their z
-     * ranges are disjoint and ascending), each rank's list already in (z, y, x) order. */
+    /* The exchange: per-(octave, level) counts, the candidates' |DoG| values and the ORIENTED
+     * keypoints -- device to device: the counts (with this rank's status word behind them) in a first
+     * all-gather, whose result the host needs to size the second; values + records in ONE block per rank in
+     * the second; the global list is then built by a kernel on every rank (sift3d_hip_slab_build: (o, s) major,
+     * ranks in slab order inside a level -- their z ranges are disjoint and ascending --, a rank's own
+     * (z, y, x) order inside its segment) and read back once. */
     {
-        int32_t *cnt = (int32_t *)calloc((size_t)nkey * 2, sizeof(int32_t));
-        int32_t *allcnt;
-        int64_t *cc, *ck;            /* per rank prefix sums over keys: candidates / kept */
-        size_t *segstart = NULL;     /* first global position of segment (key, rank) */
-        size_t nkept = 0, maxc = 0, maxk = 0, tot_c = 0, tot_k = 0;
-        float *vals;
-        sh_gkp *recs;
-        if (!cnt)
-            return SIFT3D_FAILURE;
-        /* (the host loops over the candidate and keypoint lists run on a few threads, each on a contiguous
-         * part of the list: the order of the records is the reference's scan order and is kept) */
+        const size_t cnt_bytes = ((sizeof(int32_t) * 2 * (size_t)nkey + 15) & ~(size_t)15) + 16;
+        const int W = S->world, nseg = nkey * W;
+        int32_t *h_cnt, *h_stat;
+        uint32_t *h_tab, *segk, *segc, *ck, *cc;
+        size_t maxc = 0, maxk = 0, tot_c = 0, tot_k = 0, roff, toff, blk, tab_words;
+        int any_failed = 0;
+        /* [W blocks gathered][mine] */
+        if (sh_ensure_dev(&S->d_cnt, &S->cnt_cap, cnt_bytes * (size_t)(W + 1)) ||
+            sh_ensure_pinned(&S->h_cnt, &S->hcnt_cap, cnt_bytes * (size_t)W + 64))
+            return SIFT3D_FAILURE;               /* (the exchange buffers themselves: nothing to send in) */
+        h_cnt = (int32_t *)S->h_cnt;
+        h_stat = (int32_t *)((char *)S->h_cnt + cnt_bytes * (size_t)W);      /* two words sent from here */
         {
-            const int nt = host_threads(count);
-            int32_t *tc = (int32_t *)calloc((size_t)nt * 2 * (size_t)nkey, sizeof(int32_t));
-            if (!tc) {
-                free(cnt);
-                return SIFT3D_FAILURE;
-            }
-#pragma omp parallel num_threads(nt)
-            {
-                const int nth = omp_get_num_threads(), t = omp_get_thread_num();  /* (the team's real size) */
-                const size_t lo = (size_t)count * t / nth, hi = (size_t)count * (t + 1) / nth;
-                int32_t *mine = tc + (size_t)t * 2 * nkey;
-                size_t q;
-                for (q = lo; q < hi; q++) {
-                    const int tag = S->h_cand[q].tag;
-                    const int key = (tag / S->ngl) * S->K + (tag % S->ngl - 1);
-                    mine[2 * key]++;
-                    mine[2 * key + 1] += S->h_keep[q] != 0;
-                }
-            }
-            for (r = 0; r < nt; r++)
-                for (k = 0; k < 2 * nkey; k++)
-                    cnt[k] += tc[(size_t)r * 2 * nkey + k];
-            for (k = 0; k < nkey; k++)
-                nkept += (size_t)cnt[2 * k + 1];
-            free(tc);
+            char *mine = (char *)S->d_cnt + cnt_bytes * (size_t)W;
+            SH_DO(sift3d_hip_slab_count(S->d_cand, S->d_keep, count, S->ngl, S->K, nkey, (int32_t *)mine,
+                                        S->stream));
+            h_stat[0] = S->failed;
+            SH_COMM(sift3d_hip_memcpy_h2d(mine + cnt_bytes - 16, h_stat, sizeof(int32_t), S->stream) ||
+                    sh_allgather_dev(S, mine, S->d_cnt, cnt_bytes) ||
+                    sift3d_hip_memcpy_d2h(h_cnt, S->d_cnt, cnt_bytes * (size_t)W, S->stream) ||
+                    sift3d_hip_stream_sync(S->stream));
         }
-        if (sh_allgather_host(S, cnt, sizeof(int32_t) * 2 * (size_t)nkey)) {
-            free(cnt);
+        for (r = 0; r < W; r++)
+            any_failed |= *(const int32_t *)((const char *)h_cnt + cnt_bytes * (size_t)(r + 1) - 16) != 0;
+        if (any_failed) {
+            if (S->failed)
+                ERR("sift3d_amd_sharded_detect: rank %d failed locally (mark %d) \n", S->rank, S->failed);
+            return SIFT3D_FAILURE;               /* on every rank, here */
+        }
+        /* prefix sums over keys per rank (ck kept, cc candidates), segment starts of the global orders */
+        tab_words = 2 * ((size_t)nseg + 1) + 2 * (size_t)W * (nkey + 1);
+        if (sh_ensure_pinned(&S->h_tab, &S->htab_cap, sizeof(uint32_t) * tab_words) ||
+            sh_ensure_dev(&S->d_tab, &S->tab_cap, sizeof(uint32_t) * tab_words))
             return SIFT3D_FAILURE;
-        }
-        free(cnt);
-        {
-            const size_t pad = (sizeof(int32_t) * 2 * (size_t)nkey + 15) & ~(size_t)15;
-            allcnt = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)nkey * S->world);
-            cc = (int64_t *)calloc((size_t)(nkey + 1) * S->world, sizeof(int64_t));
-            ck = (int64_t *)calloc((size_t)(nkey + 1) * S->world, sizeof(int64_t));
-            segstart = (size_t *)calloc((size_t)nkey * S->world + 1, sizeof(size_t));
-            if (!allcnt || !cc || !ck || !segstart) {
-                free(allcnt); free(cc); free(ck); free(segstart);
-                return SIFT3D_FAILURE;
+        h_tab = (uint32_t *)S->h_tab;
+        segk = h_tab; segc = segk + nseg + 1; ck = segc + nseg + 1; cc = ck + (size_t)W * (nkey + 1);
+        for (r = 0; r < W; r++) {
+            const int32_t *a = (const int32_t *)((const char *)h_cnt + cnt_bytes * (size_t)r);
+            ck[(size_t)r * (nkey + 1)] = cc[(size_t)r * (nkey + 1)] = 0;
+            for (k = 0; k < nkey; k++) {
+                cc[(size_t)r * (nkey + 1) + k + 1] = cc[(size_t)r * (nkey + 1) + k] + (uint32_t)a[2 * k];
+                ck[(size_t)r * (nkey + 1) + k + 1] = ck[(size_t)r * (nkey + 1) + k] + (uint32_t)a[2 * k + 1];
             }
-            for (r = 0; r < S->world; r++) {
-                memcpy(allcnt + (size_t)r * 2 * nkey, (char *)S->h_xchg + pad * (S->world == 1 ? 0 : r),
-                       sizeof(int32_t) * 2 * (size_t)nkey);
-                for (k = 0; k < nkey; k++) {
-                    cc[(size_t)r * (nkey + 1) + k + 1] = cc[(size_t)r * (nkey + 1) + k] + allcnt[((size_t)r * nkey + k) * 2];
-                    ck[(size_t)r * (nkey + 1) + k + 1] = ck[(size_t)r * (nkey + 1) + k] + allcnt[((size_t)r * nkey + k) * 2 + 1];
-                }
-                if ((size_t)cc[(size_t)r * (nkey + 1) + nkey] > maxc) maxc = (size_t)cc[(size_t)r * (nkey + 1) + nkey];
-                if ((size_t)ck[(size_t)r * (nkey + 1) + nkey] > maxk) maxk = (size_t)ck[(size_t)r * (nkey + 1) + nkey];
-                tot_c += (size_t)cc[(size_t)r * (nkey + 1) + nkey];
-                tot_k += (size_t)ck[(size_t)r * (nkey + 1) + nkey];
-            }
+            if (cc[(size_t)r * (nkey + 1) + nkey] > maxc) maxc = cc[(size_t)r * (nkey + 1) + nkey];
+            if (ck[(size_t)r * (nkey + 1) + nkey] > maxk) maxk = ck[(size_t)r * (nkey + 1) + nkey];
         }
+        for (k = 0; k < nkey; k++)
+            for (r = 0; r < W; r++) {
+                segc[(size_t)k * W + r] = (uint32_t)tot_c;
+                segk[(size_t)k * W + r] = (uint32_t)tot_k;
+                tot_c += cc[(size_t)r * (nkey + 1) + k + 1] - cc[(size_t)r * (nkey + 1) + k];
+                tot_k += ck[(size_t)r * (nkey + 1) + k + 1] - ck[(size_t)r * (nkey + 1) + k];
+            }
+        segc[nseg] = (uint32_t)tot_c;
+        segk[nseg] = (uint32_t)tot_k;
         S->ncand = (int)tot_c;
-        /* kept records of this rank, global coordinates */
-        recs = (sh_gkp *)calloc(maxk ? maxk : 1, sizeof(sh_gkp));
-        vals = (float *)calloc(maxc ? maxc : 1, sizeof(float));
-        if (!recs || !vals) {
-            free(recs); free(vals); free(allcnt); free(cc); free(ck); free(segstart);
+        if (S->inject == 3)
+            S->failed = -3;
+        /* this rank's block: [values of all its candidates][its kept records][status word] */
+        roff = (sizeof(float) * (maxc ? maxc : 1) + 15) & ~(size_t)15;
+        toff = roff + ((56 * (maxk ? maxk : 1) + 15) & ~(size_t)15);
+        blk = toff + 16;
+        if (sh_ensure_dev(&S->d_xchg, &S->xchg_bytes, blk * (size_t)(W + 1)) ||
+            sh_ensure_dev(&S->d_out, &S->out_cap, 64 + 64 * (tot_k ? tot_k : 1)) ||
+            sh_ensure_pinned(&S->h_xchg, &S->hxchg_cap, 64 + 64 * (tot_k ? tot_k : 1)) ||
+            sh_ensure_dev(&S->d_pack, &S->pack_cap, sift3d_hip_slab_pack_scratch_bytes(S->cand_cap)))
             return SIFT3D_FAILURE;
-        }
-        {
-            const int nt = host_threads(count);
-            size_t pre[HOST_THREADS_MAX + 1];
-            pre[0] = 0;
-#pragma omp parallel num_threads(nt)
-            {
-                const int nth = omp_get_num_threads(), t = omp_get_thread_num();
-                const size_t lo = (size_t)count * t / nth, hi = (size_t)count * (t + 1) / nth;
-                size_t q, jj = 0;
-                for (q = lo; q < hi; q++)
-                    jj += S->h_keep[q] != 0;
-                pre[t + 1] = jj;
-#pragma omp barrier
-#pragma omp single
-                {
-                    int u;
-                    for (u = 0; u < nth; u++)
-                        pre[u + 1] += pre[u];
-                }
-                /* (implicit barrier) */
-                jj = pre[t];
-                for (q = lo; q < hi; q++) {
-                    const sift3d_hip_cand *c = S->h_cand + q;
-                    const int oo = c->tag / S->ngl;
-                    const uint32_t plane = (uint32_t)sh_plane(S, oo);        /* (a level has < 2^32 voxels) */
-                    const uint32_t zq = c->idx / plane, rem = c->idx - zq * plane;
-                    vals[q] = c->val;
-                    if (!S->h_keep[q])
-                        continue;
-                    recs[jj].o = oo;
-                    recs[jj].s = c->tag % S->ngl - 1;
-                    recs[jj].x = (int32_t)(rem % (uint32_t)S->dims[oo][0]);
-                    recs[jj].y = (int32_t)(rem / (uint32_t)S->dims[oo][0]);
-                    recs[jj].z = (int32_t)zq + S->G[oo][0].off;
-                    memcpy(recs[jj].R, S->h_R + 9 * q, sizeof(recs[jj].R));
-                    jj++;
-                }
-            }
-        }
         /* keypoint store: dimensions of the first octave (sift.c:756-759) */
         kp->nx = S->nx; kp->ny = S->ny; kp->nz = S->nz;
-        if (kp_store_resize(kp, tot_k)) {
-            free(recs); free(vals); free(allcnt); free(cc); free(ck); free(segstart);
-            return SIFT3D_FAILURE;
+        SH_DO(kp_store_resize(kp, tot_k));
+        {
+            char *mine = (char *)S->d_xchg + blk * (size_t)W;
+            SH_DO(sift3d_hip_memcpy_h2d(S->d_tab, h_tab, sizeof(uint32_t) * tab_words, S->stream));
+            SH_DO(sift3d_hip_slab_pack(S->d_levels, S->d_cand, S->d_keep, S->d_R, count, S->ngl, (float *)mine,
+                                       mine + roff, S->d_pack, S->stream));
+            h_stat[1] = S->failed;
+            SH_COMM(sift3d_hip_memcpy_h2d(mine + toff, h_stat + 1, sizeof(int32_t), S->stream) ||
+                    sh_allgather_dev(S, mine, S->d_xchg, blk));
+            /* (copy_Keypoint omits `strength`, sift.c:372-384: slot j keeps GLOBAL candidate j's value) */
+            SH_DO(sift3d_hip_slab_build(S->d_xchg, blk, roff, toff, W, nkey, (const uint32_t *)S->d_tab,
+                                        (uint32_t)tot_k, (uint32_t)tot_c, S->d_out, S->stream));
+            SH_COMM(sift3d_hip_memcpy_d2h(S->h_xchg, S->d_out, 64 + 64 * tot_k, S->stream) ||
+                    sift3d_hip_stream_sync(S->stream));
         }
-        /* values first (the staging buffer is reused): copy_Keypoint omits `strength`
-         * (sift.c:372-384), so slot j keeps GLOBAL candidate j's value (quirk Q2): only the first
-         * tot_k values of the global candidate order matter */
-        if (sh_allgather_host(S, vals, sizeof(float) * (maxc ? maxc : 1))) {
-            free(recs); free(vals); free(allcnt); free(cc); free(ck); free(segstart);
-            return SIFT3D_FAILURE;
+        if (S->failed || *(const int32_t *)S->h_xchg != 0) {
+            if (S->failed)
+                ERR("sift3d_amd_sharded_detect: rank %d failed locally (mark %d) \n", S->rank, S->failed);
+            return SIFT3D_FAILURE;               /* on every rank: the status words are in everybody's list */
         }
         {
-            /* segment (k, r) of the global candidate order starts at cstart[k * world + r] */
-            const size_t pad = (sizeof(float) * (maxc ? maxc : 1) + 15) & ~(size_t)15;
-            const int nseg = nkey * S->world;
-            int sg;
-            size_t got = 0;
+            /* the records into the store: a few threads, each on a contiguous part; a segment holds one
+             * (octave, level), i.e. one scale (imutil.c:1578-1579) */
+            const sh_out *rec = (const sh_out *)((const char *)S->h_xchg + 64);
+            const int nt = host_threads(tot_k);
+            double sdk[256];
             for (k = 0; k < nkey; k++)
-                for (r = 0; r < S->world; r++) {
-                    segstart[(size_t)k * S->world + r] = got;
-                    got += (size_t)(cc[(size_t)r * (nkey + 1) + k + 1] - cc[(size_t)r * (nkey + 1) + k]);
-                }
-#pragma omp parallel for num_threads(host_threads(tot_k)) schedule(dynamic, 1)
-            for (sg = 0; sg < nseg; sg++) {
-                const int kk_ = sg / S->world, rr = sg % S->world;
-                const float *v = (const float *)((char *)S->h_xchg + pad * (S->world == 1 ? 0 : rr));
-                const int64_t q0 = cc[(size_t)rr * (nkey + 1) + kk_], q1 = cc[(size_t)rr * (nkey + 1) + kk_ + 1];
-                size_t g = segstart[sg];
-                int64_t q;
-                for (q = q0; q < q1 && g < tot_k; q++)
-                    kp->buf[g++].strength = v[q];
-            }
-        }
-        if (sh_allgather_host(S, recs, sizeof(sh_gkp) * (maxk ? maxk : 1))) {
-            free(recs); free(vals); free(allcnt); free(cc); free(ck); free(segstart);
-            return SIFT3D_FAILURE;
-        }
-        {
-            const size_t pad = (sizeof(sh_gkp) * (maxk ? maxk : 1) + 15) & ~(size_t)15;
-            const int nseg = nkey * S->world;
-            int sg;
-            size_t got = 0;
-            for (k = 0; k < nkey; k++)
-                for (r = 0; r < S->world; r++) {
-                    segstart[(size_t)k * S->world + r] = got;
-                    got += (size_t)(ck[(size_t)r * (nkey + 1) + k + 1] - ck[(size_t)r * (nkey + 1) + k]);
-                }
-#pragma omp parallel for num_threads(host_threads(tot_k)) schedule(dynamic, 1)
-            for (sg = 0; sg < nseg; sg++) {
-                const int kk_ = sg / S->world, rr = sg % S->world;
-                const sh_gkp *g = (const sh_gkp *)((char *)S->h_xchg + pad * (S->world == 1 ? 0 : rr));
-                const int64_t q0 = ck[(size_t)rr * (nkey + 1) + kk_], q1 = ck[(size_t)rr * (nkey + 1) + kk_ + 1];
-                /* a segment holds one (octave, level): one scale (imutil.c:1578-1579) */
-                const double sd = sh_scale(S, kk_ / S->K, kk_ % S->K);
-                keypoint_t *kk = kp->buf + segstart[sg];
-                int64_t q;
-                for (q = q0; q < q1; q++, kk++) {
-                    kk->o = g[q].o; kk->s = g[q].s;
-                    kk->xd = g[q].x; kk->yd = g[q].y; kk->zd = g[q].z;
-                    kk->sd = sd;
-                    memcpy(kk->R, g[q].R, sizeof(kk->R));
+                sdk[k] = sh_scale(S, k / S->K, k % S->K);
+#pragma omp parallel num_threads(nt)
+            {
+                const int nth = omp_get_num_threads(), t = omp_get_thread_num();   /* (the team's real size) */
+                const size_t lo = tot_k * (size_t)t / nth, hi = tot_k * (size_t)(t + 1) / nth;
+                size_t g;
+                for (g = lo; g < hi; g++) {
+                    keypoint_t *kk = kp->buf + g;
+                    kk->o = rec[g].o; kk->s = rec[g].s;
+                    kk->xd = rec[g].x; kk->yd = rec[g].y; kk->zd = rec[g].z;
+                    kk->sd = sdk[rec[g].o * S->K + rec[g].s];
+                    memcpy(kk->R, rec[g].R, sizeof(kk->R));
+                    kk->strength = rec[g].strength;
                 }
             }
         }
-        free(recs); free(vals); free(allcnt); free(cc); free(ck); free(segstart);
     }
     S->t[0] = 1e-3 * sift3d_hip_event_elapsed_ms(S->ev0, S->ev1);
     S->t[3] = 1e-3 * sift3d_hip_event_elapsed_ms(S->ev1, S->ev2);
@@ -1258,6 +1210,131 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
             return SIFT3D_FAILURE;
     }
     S->t[2] = now_s() - t_start;
+    return SIFT3D_SUCCESS;
+}
+
+/* ---- descriptor gather ("computed by the owning rank and gathered (N x 771 f32)") ---- */
+int sift3d_amd_sharded_gather_descriptors(sift3d_amd_sharded *S, const sift3d_keypoint_store *kp,
+                                          const sift3d_descriptor_store *own, const int *own_idx, int n_own,
+                                          sift3d_descriptor_store *all, int root)
+{
+    const int W = S ? S->world : 0;
+    size_t num, maxn = 0, blk, q;
+    size_t cnt[SH_MAX_WORLD];
+    uint32_t *map = NULL;
+    int32_t *h_stat;
+    int r, want, failed = 0, any = 0;
+    if (!S || !kp || !own || !all || (n_own > 0 && !own_idx) || root >= W)
+        return SIFT3D_FAILURE;
+    num = kp->num;
+    want = root < 0 || root == S->rank;
+    if (S->inject == 4)
+        failed = -4;
+    /* who owns which keypoint follows from the list and the slab bounds: every rank derives every rank's
+     * rows (the rule of sift3d_amd_sharded_describe) */
+    memset(cnt, 0, sizeof(cnt));
+    map = (uint32_t *)malloc(sizeof(uint32_t) * (num ? num : 1));
+    if (!map)
+        failed = failed ? failed : __LINE__;
+    for (q = 0; q < num && map; q++) {
+        const keypoint_t *k = kp->buf + q;
+        int rr = 0;
+        if (k->o < 0 || k->o >= S->num_octaves) {
+            failed = failed ? failed : __LINE__;
+            map[q] = 0;
+            continue;
+        }
+        if (W > 1)
+            for (rr = 0; rr < W - 1; rr++)
+                if (k->zd < (double)S->bounds[k->o][rr + 1])
+                    break;
+        map[q] = ((uint32_t)rr << 24) | (uint32_t)(cnt[rr] & 0xffffffu);
+        cnt[rr]++;
+    }
+    for (r = 0; r < W; r++)
+        if (cnt[r] > maxn)
+            maxn = cnt[r];
+    if (maxn >= (1u << 24))
+        return SIFT3D_FAILURE;                         /* (the same on every rank) */
+    if (!failed && (size_t)(n_own < 0 ? 0 : n_own) != cnt[S->rank])
+        failed = __LINE__;                             /* desc_own is not this rank's describe result */
+    if (!failed && (own->num != cnt[S->rank] || (cnt[S->rank] && !own->hist)))
+        failed = __LINE__;
+    blk = DESC_NUMEL * sizeof(float) * (maxn ? maxn : 1) + 16;
+    if (sh_ensure_dev(&S->d_gath, &S->gath_cap, blk * (size_t)(W + 1)) ||
+        sh_ensure_pinned(&S->h_cnt, &S->hcnt_cap, 16 * (size_t)W + 64)) {
+        free(map);
+        return SIFT3D_FAILURE;                         /* (the exchange buffers themselves) */
+    }
+    h_stat = (int32_t *)((char *)S->h_cnt + 16 * (size_t)W);
+    {
+        char *mine = (char *)S->d_gath + blk * (size_t)W;
+        if (!failed && cnt[S->rank] &&
+            sift3d_hip_memcpy_h2d(mine, own->hist, DESC_NUMEL * sizeof(float) * cnt[S->rank], S->stream))
+            failed = __LINE__;
+        h_stat[0] = failed;
+        if (sift3d_hip_memcpy_h2d(mine + blk - 16, h_stat, sizeof(int32_t), S->stream) ||
+            sh_allgather_dev(S, mine, S->d_gath, blk) ||
+            sift3d_hip_memcpy2d_d2h(S->h_cnt, 16, (char *)S->d_gath + blk - 16, blk, 16, (size_t)W, S->stream) ||
+            sift3d_hip_stream_sync(S->stream)) {
+            free(map);
+            return SIFT3D_FAILURE;
+        }
+    }
+    for (r = 0; r < W; r++)
+        any |= *(const int32_t *)((const char *)S->h_cnt + 16 * (size_t)r) != 0;
+    if (any) {
+        if (failed)
+            ERR("sift3d_amd_sharded_gather_descriptors: rank %d failed locally (mark %d) \n", S->rank, failed);
+        free(map);
+        return SIFT3D_FAILURE;                         /* on every rank, here */
+    }
+    if (want) {
+        /* rows into the global order on the device, one copy into the store's page-locked array */
+        const size_t cap = num + num / 8 + 64;
+        void *d_map = NULL, *d_rows = NULL;
+        int rc = SIFT3D_SUCCESS;
+        if (!all->pinned || num > all->cap) {
+            desc_store_release(all);
+            all->hist = (float *)sift3d_hip_host_alloc(sizeof(float) * DESC_NUMEL * cap);
+            all->xyzsd = (double *)malloc(sizeof(double) * 4 * cap);
+            if (!all->hist || !all->xyzsd) {
+                all->pinned = all->hist != NULL;
+                desc_store_release(all);
+                free(map);
+                return SIFT3D_FAILURE;
+            }
+            all->pinned = 1;
+            all->cap = cap;
+        }
+        all->nx = S->nx; all->ny = S->ny; all->nz = S->nz;
+        all->num = num;
+        all->d_num = 0;
+        if (num) {
+            d_map = sift3d_hip_malloc(sizeof(uint32_t) * num);
+            d_rows = sift3d_hip_malloc(sizeof(float) * DESC_NUMEL * num);
+            if (!d_map || !d_rows ||
+                sift3d_hip_memcpy_h2d(d_map, map, sizeof(uint32_t) * num, S->stream) ||
+                sift3d_hip_rows_scatter((float *)d_rows, S->d_gath, blk, (const uint32_t *)d_map, (uint32_t)num,
+                                        S->stream) ||
+                sift3d_hip_memcpy_d2h(all->hist, d_rows, sizeof(float) * DESC_NUMEL * num, S->stream) ||
+                sift3d_hip_stream_sync(S->stream))
+                rc = SIFT3D_FAILURE;
+            sift3d_hip_free(d_map);
+            sift3d_hip_free(d_rows);
+        }
+        for (q = 0; q < num; q++) {
+            const keypoint_t *k = kp->buf + q;
+            const double f = ldexp(1.0, k->o);             /* sift.c:1459, 1530-1533 */
+            all->xyzsd[4 * q] = k->xd * f;
+            all->xyzsd[4 * q + 1] = k->yd * f;
+            all->xyzsd[4 * q + 2] = k->zd * f;
+            all->xyzsd[4 * q + 3] = k->sd;
+        }
+        free(map);
+        return rc;
+    }
+    free(map);
     return SIFT3D_SUCCESS;
 }
 

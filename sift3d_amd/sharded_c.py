@@ -64,6 +64,9 @@ def _lib():
         L.sift3d_amd_sharded_detect.argtypes = [vp, vp]
         L.sift3d_amd_sharded_describe.argtypes = [vp, vp, vp, np.ctypeslib.ndpointer(np.int32),
                                                   C.POINTER(C.c_int)]
+        L.sift3d_amd_sharded_gather_descriptors.argtypes = [vp, vp, vp, np.ctypeslib.ndpointer(np.int32), C.c_int,
+                                                            vp, C.c_int]
+        L.sift3d_amd_sharded_inject_failure.argtypes = [vp, C.c_int]
         L.sift3d_amd_sharded_num_candidates.argtypes = [vp]
         L.sift3d_amd_sharded_timings.restype = C.POINTER(C.c_double)
         L.sift3d_amd_sharded_timings.argtypes = [vp]
@@ -381,6 +384,21 @@ class CShardedSift3D:
                                % hip.lib().sift3d_hip_last_error().decode())
         self.own_idx = idx[:cnt.value].copy()
         return self.own_idx, self.desc_store
+
+    def gather_descriptors(self, root=-1):
+        """The descriptors of ALL keypoints in the global order (N x 771 through DescriptorStore.to_mat_rm):
+        on every rank (root < 0) or on rank `root` only (the others return None).  Collective."""
+        allstore = api.DescriptorStore()
+        idx = self.own_idx if len(self.own_idx) else np.zeros(1, np.int32)
+        if _lib().sift3d_amd_sharded_gather_descriptors(self.h, self.kp_store.h, self.desc_store.h, idx,
+                                                        len(self.own_idx), allstore.h, int(root)) != 0:
+            raise RuntimeError("sift3d_amd_sharded_gather_descriptors failed")
+        return allstore if root < 0 or root == self.rank else None
+
+    def inject_failure(self, where):
+        """Test hook: the next detect (1, 2, 3) / descriptor gather (4) of this rank fails locally; 0 clears."""
+        if _lib().sift3d_amd_sharded_inject_failure(self.h, int(where)) != 0:
+            raise ValueError("sift3d_amd_sharded_inject_failure(%r)" % (where,))
 
     def keypoints(self):
         """Global keypoint list as the Python driver's record array."""

@@ -293,6 +293,116 @@ def test_c_slab_driver_over_stream_ordered_transport(world, dims, det_kw):
     np.testing.assert_array_equal(covered, 1)
 
 
+def _thread_ranks(world, dims, body, transport="stream", seed=5):
+    """Run body(rank, job) on `world` C slab drivers, each a thread of this process; returns body's results."""
+    import threading
+    from sift3d_amd import api, sharded_c
+    nx, ny, nz = dims
+    group = sharded_c.StreamThreadGroup(world) if transport == "stream" else sharded_c.ThreadGroup(world)
+    make = sharded_c.StreamThreadTransport if transport == "stream" else sharded_c.ThreadTransport
+    vol = api.synth_lattice(dims, seed=seed)
+    out, err = [None] * world, []
+
+    def run(rank):
+        try:
+            tr = make(group, rank)
+            job = sharded_c.CShardedSift3D(nx, ny, nz, tr)
+            z0, z1 = job.in_own
+            job.set_local_volume(vol[z0:z1])
+            out[rank] = body(rank, job)
+            job.close()
+            tr.close()
+        except Exception as e:  # noqa: BLE001
+            err.append((rank, repr(e)))
+            try:
+                group.barrier.abort()
+            except Exception:
+                pass
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(900)
+    if transport == "stream":
+        group.close()
+    assert not err, err
+    return out, vol
+
+
+@pytest.mark.parametrize("root", [-1, 1])
+def test_descriptor_gather_equals_single_gpu(root):
+    """sift3d_amd_sharded_gather_descriptors (descriptors computed by the owning rank and
+    gathered, N x 771 f32): the matrix in the global keypoint order, on every rank or on one root, equals
+    the single-GPU drop-in API's bit for bit."""
+    import torch
+    from sift3d_amd import api
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    world, dims = 3, (64, 72, 288)
+
+    def body(rank, job):
+        job.detect()
+        job.describe()
+        g = job.gather_descriptors(root)
+        return None if g is None else g.to_mat_rm()
+
+    out, vol = _thread_ranks(world, dims, body)
+    det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+    assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
+    assert det.extract_descriptors(kp, desc) == 0
+    m = desc.to_mat_rm()
+    assert len(m) > 50
+    for r in range(world):
+        if root < 0 or r == root:
+            np.testing.assert_array_equal(out[r], m, err_msg="rank %d" % r)
+        else:
+            assert out[r] is None
+
+
+@pytest.mark.parametrize("where", [1, 2, 3, 4])
+def test_rank_local_failure_returns_failure_on_every_rank(where):
+    """A failure that ONE rank meets between two exchanges (injected: before the pyramid, after the extrema,
+    between the two all-gathers of detect, in the descriptor gather) must come back as SIFT3D_FAILURE from
+    the same call on EVERY rank -- the failing rank keeps issuing the step's exchanges, its status word
+    travels behind the gathered blocks -- and leave the transport in step: the next, clean call succeeds
+    everywhere with the right result (the reference: every stage returns -1, immacros.h:27-32)."""
+    import torch
+    from sift3d_amd import api
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    world, dims, bad = 3, (48, 48, 320), 1
+
+    def body(rank, job):
+        failed = None
+        if rank == bad:
+            job.inject_failure(where)
+        try:
+            job.detect()
+            job.describe()
+            job.gather_descriptors(-1)
+            failed = False
+        except RuntimeError:
+            failed = True
+        job.inject_failure(0)
+        job.detect()
+        job.describe()
+        g = job.gather_descriptors(-1)
+        return failed, job.keypoints(), g.to_mat_rm()
+
+    out, vol = _thread_ranks(world, dims, body)
+    det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+    assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
+    assert det.extract_descriptors(kp, desc) == 0
+    k, m = kp.records(), desc.to_mat_rm()
+    for r in range(world):
+        failed, kk, mm = out[r]
+        assert failed is True, "rank %d did not see rank %d's failure" % (r, bad)
+        for f in ("o", "s", "xd", "yd", "zd", "sd", "strength", "R"):
+            np.testing.assert_array_equal(kk[f], k[f], err_msg="rank %d field %s" % (r, f))
+        np.testing.assert_array_equal(mm, m)
+
+
 def _check_against_reference_fixture(g, kp, mat_rows, idx, ncand):
     """A rank's results against the reference's own run of the volume (tests/golden/g5_256x256x1024.npz,
     made by oracle/make_golden.py from the unmodified reference): keypoint fields and R by digest,
