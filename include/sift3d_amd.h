@@ -62,6 +62,11 @@ sift3d_amd_detector_set_cuboid_extrema(sift3d_detector *det, int on);
  * sift3d_hip_extrema_gauss6_est_phase).  Same candidates either way; an A/B switch for tests and profiles. */
 SIFT3D_AMD_API int
 sift3d_amd_detector_set_dogmax_pass(sift3d_detector *det, int on);
+/* Orientation window sums: 0 (default) = parallel sums with decisions by margin and a serial re-run of the
+ * undecided candidates; non-zero = the reference's serial sums (sift.c:978-990) for every candidate.  Same
+ * keypoints and R bit for bit either way; an A/B switch for tests and profiles. */
+SIFT3D_AMD_API int
+sift3d_amd_detector_set_serial_orientation(sift3d_detector *det, int on);
 /* Descriptor accumulation (sift3d_extract_descriptors): 0 (default) = automatic: keypoints whose window
  * holds more than ~1.9e5 voxels -- sigma0 * 2^(s/K) above ~2.9 voxels, never with the default parameters --
  * are computed in the reference's accumulation order (their histograms are the reference's bit for bit),
@@ -504,10 +509,7 @@ SIFT3D_AMD_API int
 sift3d_hip_orient_tab(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_cand *d_cand,
                       uint32_t n, double corner_thresh, float *d_R, int32_t *d_keep, void *d_tab,
                       uint32_t max_cand, void *stream);
-/* 1: sift3d_hip_orient_tab runs the serial sums for every candidate (= sift3d_hip_orient); 0
- * (default): as described above.  Returns the previous mode; any other argument only queries.
- * Process-wide (tests, A/B measurements). */
-SIFT3D_AMD_API int sift3d_hip_orient_mode(int mode);
+/* (d_tab = NULL: the serial sums for every candidate, = sift3d_hip_orient) */
 
 typedef struct {
     float R[9];

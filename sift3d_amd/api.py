@@ -75,6 +75,7 @@ def lib():
         "sift3d_amd_detector_set_cuboid_extrema": (C.c_int, [vp, C.c_int]),
         "sift3d_amd_detector_set_dogmax_pass": (C.c_int, [vp, C.c_int]),
         "sift3d_amd_detector_set_exact_descriptors": (C.c_int, [vp, C.c_int]),
+        "sift3d_amd_detector_set_serial_orientation": (C.c_int, [vp, C.c_int]),
         "sift3d_amd_detector_dogmax": (C.c_int, [vp, vp, C.c_int]),
         "sift3d_amd_copy_level": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, _i32p]),
         "sift3d_amd_keypoint_store_size": (C.c_int, [vp]),
@@ -349,6 +350,10 @@ class Detector:
     def set_cuboid_extrema(self, on):
         """Run-time form of the reference's compile-time CUBOID_EXTREMA (sift.c:24)."""
         return lib().sift3d_amd_detector_set_cuboid_extrema(self.h, int(bool(on)))
+
+    def set_serial_orientation(self, on):
+        """A/B switch: the reference's serial window sums for every candidate (same results bit for bit)."""
+        return lib().sift3d_amd_detector_set_serial_orientation(self.h, int(bool(on)))
 
     def set_exact_descriptors(self, mode):
         """0: automatic (wide windows in the reference's accumulation order), 1: always (descriptors bit-exact

@@ -27,6 +27,7 @@
 #include <time.h>
 #include <zlib.h>
 #include <omp.h>
+#include <dlfcn.h>
 #include <pthread.h>
 
 #include "../../include/sift3d/imutil.h"
@@ -133,6 +134,7 @@ struct _sift3d_detector {
     float *d_scalars;      /* [0] input max, [1] count (as u32), [8 + o*ndl + s] dogmax, then
                             * [8 + (num_octaves + o)*ndl + s] their lower bounds (sift3d_hip_dogmax_sub) */
     int t_pending;         /* stage events not yet read into t[]: 1 detect, 2 describe */
+    int orient_serial;     /* sift3d_amd_detector_set_serial_orientation */
     int exact_desc;        /* sift3d_amd_detector_set_exact_descriptors: 0 auto, 1 always, -1 never */
     int im_valid;          /* d_im holds the scaled image of the last detect call (else: see last_vol) */
     const float *last_vol; /* the last detect call's volume on the device (the caller's, or d_in) */
@@ -1076,6 +1078,14 @@ int sift3d_amd_detector_set_dogmax_pass(sift3d_detector *d, int on)
     return SIFT3D_SUCCESS;
 }
 
+int sift3d_amd_detector_set_serial_orientation(sift3d_detector *d, int on)
+{
+    if (!d)
+        return SIFT3D_FAILURE;
+    d->orient_serial = on != 0;
+    return SIFT3D_SUCCESS;
+}
+
 int sift3d_amd_detector_set_exact_descriptors(sift3d_detector *d, int mode)
 {
     if (!d || mode < -1 || mode > 1)
@@ -1248,6 +1258,50 @@ int sift3d_amd_detector_dogmax(const sift3d_detector *d, float *out, int cap)
         sift3d_hip_stream_sync(d->stream))
         return -1;
     return n;
+}
+
+/* ------------------------------------------------------------------------ */
+/* tracing: roctx ranges around the stages (rocprofv3 --marker-trace) */
+/* ------------------------------------------------------------------------ */
+/* The marker library is loaded at run time, at the first call; without it the ranges cost a pointer
+ * test.  Ranges are started / stopped by id, so a call that fails half-way leaves no unbalanced
+ * stack behind. */
+static struct {
+    pthread_once_t once;
+    uint64_t (*start)(const char *);
+    void (*stop)(uint64_t);
+} g_roctx = { PTHREAD_ONCE_INIT, NULL, NULL };
+
+static void roctx_load(void)
+{
+    /* (rocprofv3's marker library first, the roctracer one as a fallback; SIFT3D_AMD_ROCTX=0 disables) */
+    static const char *names[] = { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so",
+                                   "libroctx64.so.4", "libroctx64.so" };
+    void *lib = NULL;
+    size_t i;
+    const char *e = getenv("SIFT3D_AMD_ROCTX");
+    if (e && e[0] == '0')
+        return;
+    for (i = 0; i < sizeof(names) / sizeof(names[0]) && !lib; i++)
+        lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!lib)
+        return;
+    *(void **)(&g_roctx.start) = dlsym(lib, "roctxRangeStartA");
+    *(void **)(&g_roctx.stop) = dlsym(lib, "roctxRangeStop");
+    if (!g_roctx.start || !g_roctx.stop)
+        g_roctx.start = NULL;
+}
+
+static uint64_t range_start(const char *name)
+{
+    pthread_once(&g_roctx.once, roctx_load);
+    return g_roctx.start ? g_roctx.start(name) : 0;
+}
+
+static void range_stop(uint64_t id)
+{
+    if (g_roctx.start)
+        g_roctx.stop(id);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1445,6 +1499,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                              !d->num_octaves;
     const double t_start = now_s();
     uint32_t count = 0;
+    uint64_t rng;
     int o, s, attempt, side, im_stored = 0;
 
     /* set_im_SIFT3D, sift.c:629-659 */
@@ -1464,6 +1519,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                               sizeof(sift3d_hip_level) * (size_t)d->num_octaves * d->ngl, d->stream))
         return SIFT3D_FAILURE;
 
+    rng = range_start("sift3d: max|v|");
     sift3d_hip_event_record(d->ev[0], d->stream);
     if (sift3d_hip_memset(d->d_scalars, 0, sizeof(float) * (8 + 2 * (size_t)d->num_octaves * d->ndl),
                           d->stream) ||
@@ -1475,6 +1531,8 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
      * not stored (8 B/voxel less; sift3d_amd_copy_level forms it on demand from `last_vol`).  Where the x
      * pass cannot do that (other tap spacings) the image is scaled first, as before. */
     d->yz_timed = 0;
+    range_stop(rng);
+    rng = range_start("sift3d: Gaussian pyramid");
     sift3d_hip_event_record(d->ev[1], d->stream);
     {
         double lu[3];
@@ -1559,6 +1617,8 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
             return SIFT3D_FAILURE;
     }
     sift3d_hip_event_record(d->ev[2], d->stream);
+    range_stop(rng);
+    rng = range_start("sift3d: DoG maxima");
 
     /* build_dog (sift.c:713-732) + the dogmax scan (sift.c:821-826).  Default configuration: only
      * the maxima are computed here; the extrema sweep forms the differences itself and no DoG
@@ -1615,6 +1675,8 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                  sift3d_hip_stream_wait_event(d->stream, d->ev_join)))
         return SIFT3D_FAILURE;
     sift3d_hip_event_record(d->ev[3], d->stream);
+    range_stop(rng);
+    rng = range_start("sift3d: extrema");
 
     /* detect_extrema, sift.c:735-871 */
     if (d->ndl < 3) {
@@ -1704,6 +1766,8 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     }
     sift3d_hip_event_record(d->ev[4], d->stream);
     d->ncand = (int)count;
+    range_stop(rng);
+    rng = range_start("sift3d: orientation");
 
     /* assign_orientations, sift.c:1109-1167 */
     if (count) {
@@ -1728,12 +1792,13 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
             sift3d_hip_memcpy_d2h(d->h_cand, d->d_cand, sizeof(sift3d_hip_cand) * (size_t)count,
                                   d->oct_stream) ||
             sift3d_hip_orient_tab(d->d_levels, d->num_octaves * d->ngl, d->d_cand, count, d->corner_thresh,
-                                  r_view, k_view, d->d_otab, d->cand_cap, d->stream))
+                                  r_view, k_view, d->orient_serial ? NULL : d->d_otab, d->cand_cap, d->stream))
             return SIFT3D_FAILURE;
     }
     sift3d_hip_event_record(d->ev[5], d->stream);
     if (sift3d_hip_stream_sync(d->stream) || (count && sift3d_hip_stream_sync(d->oct_stream)))
         return SIFT3D_FAILURE;
+    range_stop(rng);
 
     /* keypoint store: dimensions of the first octave (sift.c:756-759), then the in-place
      * compaction of assign_orientations.  copy_Keypoint does not copy `strength`
@@ -1853,6 +1918,7 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
     const double t_start = now_s();
     int i, lvbad = 0, lv_exact = 0;
     size_t n_exact = 0;
+    uint64_t rng;
 
     /* verify_keys, sift.c:1171-1212 (against the retained image dimensions) */
     if (num < 1) {
@@ -1992,6 +2058,7 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
         desc->d_cap = desc->cap;
     }
     d->t_pending &= ~2;
+    rng = range_start("sift3d: descriptors");
     sift3d_hip_event_record(d->ev[6], d->stream);
     /* (the kernel reads the 64-byte record of a keypoint once, as its wave starts: straight from the
      * page-locked host list -- no copy, no DMA set-up between the host loops and the launch) */
@@ -2020,6 +2087,7 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
     }
     if (sift3d_hip_stream_sync(d->stream))
         return SIFT3D_FAILURE;
+    range_stop(rng);
     if (desc->keep_device)
         desc->d_num = (size_t)num;
     d->t_pending |= 2;

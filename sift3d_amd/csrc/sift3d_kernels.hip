@@ -2109,7 +2109,7 @@ __device__ __forceinline__ void orient_serial(const sift3d_hip_level *__restrict
 __device__ unsigned long long g_orient_undecided;   // candidates re-run by k_orient_fix (profiles/)
 #endif
 
-// every candidate with the reference's serial sums (the original path; sift3d_hip_orient_mode(1))
+// every candidate with the reference's serial sums (the original path: sift3d_hip_orient, or sift3d_hip_orient_tab without a table)
 __global__ __launch_bounds__(64) void k_orient(const sift3d_hip_level *__restrict__ levels,
                                                const sift3d_hip_cand *__restrict__ cand, uint32_t n,
                                                double corner_thresh, float *__restrict__ Rout,
@@ -3446,16 +3446,6 @@ __attribute__((visibility("default"))) unsigned long long sift3d_amd_diag_orient
 }
 #endif
 
-static int g_orient_mode = 0;
-
-int sift3d_hip_orient_mode(int mode)
-{
-    const int prev = g_orient_mode;
-    if (mode == 0 || mode == 1)
-        g_orient_mode = mode;
-    return prev;
-}
-
 int sift3d_hip_orient(const sift3d_hip_level *d_levels, const sift3d_hip_cand *d_cand, uint32_t n,
                       double corner_thresh, float *d_R, int32_t *d_keep, void *stream)
 {
@@ -3487,7 +3477,7 @@ int sift3d_hip_orient_tab(const sift3d_hip_level *d_levels, int nlevels, const s
 {
     if (!n)
         return SIFT3D_SUCCESS;
-    if (g_orient_mode == 1 || !d_tab || nlevels < 1 || nlevels > ORI_PLAN_MAX || n > max_cand)
+    if (!d_tab || nlevels < 1 || nlevels > ORI_PLAN_MAX || n > max_cand)
         return sift3d_hip_orient(d_levels, d_cand, n, corner_thresh, d_R, d_keep, stream);
     // window tables of all levels, parallel sums with decisions by margin, then the undecided
     // candidates with the serial sums

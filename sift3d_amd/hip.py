@@ -85,7 +85,6 @@ def lib():
         "sift3d_hip_extrema_mode": (C.c_int, [C.POINTER(ExtremaLevel), C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_double, C.c_int, vp, C.c_uint32, vp, vp, C.c_size_t, vp]),
         "sift3d_hip_orient": (C.c_int, [vp, vp, C.c_uint32, C.c_double, vp, vp, vp]),
-        "sift3d_hip_orient_mode": (C.c_int, [C.c_int]),
         "sift3d_hip_orient_tab_bytes": (C.c_size_t, [C.c_int, C.c_uint32]),
         "sift3d_hip_orient_tab": (C.c_int, [vp, C.c_int, vp, C.c_uint32, C.c_double, vp, vp, vp, C.c_uint32, vp]),
         "sift3d_hip_describe": (C.c_int, [vp, vp, C.c_uint32, vp, vp]),
@@ -249,11 +248,6 @@ def extrema(levels, nx, ny, nz, peak_thresh, cap=1 << 18, cuboid=False):
         cap = n + n // 4 + 1024
     return out[:n * CAND_DTYPE.itemsize].cpu().numpy().view(CAND_DTYPE).copy()
 
-
-def orient_mode(mode=-1):
-    """0: parallel window sums + serial re-run of the undecided candidates (default); 1: serial
-    sums for every candidate.  Returns the previous mode (-1 only queries)."""
-    return lib().sift3d_hip_orient_mode(int(mode))
 
 
 def orient(d_levels, cands, corner_thresh):

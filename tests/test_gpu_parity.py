@@ -519,7 +519,7 @@ def test_read_image_then_detect(gpu, oracle_mod, tmp_path):
 
 @pytest.mark.parametrize("case", ["lattice160", "survey96", "aniso", "corner0", "params", "wide"])
 def test_orientation_parallel_sums_equal_serial_sums(gpu, oracle_mod, case):
-    """sift3d_hip_orient_mode: the default path (parallel double sums, decisions by margin, serial
+    """sift3d_amd_detector_set_serial_orientation: the default path (parallel double sums, decisions by margin, serial
     re-run of the undecided candidates) must give the keypoint list AND the R bits of the path
     that adds every window in the reference's scan order (sift.c:978-990)."""
     api, hip, torch = gpu
@@ -540,14 +540,11 @@ def test_orientation_parallel_sums_equal_serial_sums(gpu, oracle_mod, case):
         vol, kw = oracle_mod.synth_survey(64), dict(num_kp_levels=2, sigma0=2.0, sigma_n=1.0,
                                                     peak_thresh=0.05, corner_thresh=0.3)
     got = {}
-    try:
-        for mode in (1, 0):
-            hip.orient_mode(mode)
-            det, kp = api.Detector(**kw), api.KeypointStore()
-            assert det.detect_keypoints(api.Image.from_array(vol, units=units), kp) == 0
-            got[mode] = (det.num_candidates(), kp.records())
-    finally:
-        hip.orient_mode(0)
+    for mode in (1, 0):
+        det, kp = api.Detector(**kw), api.KeypointStore()
+        assert det.set_serial_orientation(mode) == 0
+        assert det.detect_keypoints(api.Image.from_array(vol, units=units), kp) == 0
+        got[mode] = (det.num_candidates(), kp.records())
     assert got[0][0] == got[1][0] and len(got[0][1]) == len(got[1][1]) > 0
     for f in ("o", "s", "xd", "yd", "zd", "sd", "strength", "R"):
         np.testing.assert_array_equal(got[0][1][f], got[1][1][f], err_msg=f)
