@@ -136,6 +136,7 @@ __device__ __forceinline__ int icos_guess(float rx, float ry, float rz)
 // t * WL_STRIDE: [0] 1.0f if the level qualifies, [1] the level's sd as float bits (2 floats),
 // entries from [4].
 constexpr int WL_STRIDE = 4096, WL_HEAD = 4;
+constexpr int WL_COUNTERS = 16;   // uint32 work counters behind the tables (one per descriptor launch)
 
 __global__ __launch_bounds__(256) void k_desc_wlut(const sift3d_hip_level *__restrict__ levels, int nlevels,
                                                    float *__restrict__ lut)
@@ -143,6 +144,8 @@ __global__ __launch_bounds__(256) void k_desc_wlut(const sift3d_hip_level *__res
     const int t = blockIdx.x;
     if (t >= nlevels)
         return;
+    if (t == 0 && threadIdx.x < WL_COUNTERS)   // the work counters of the descriptor launches that follow
+        reinterpret_cast<uint32_t *>(lut + (size_t)nlevels * WL_STRIDE)[threadIdx.x] = 0u;
     const sift3d_hip_level L = levels[t];
     float *tab = lut + (size_t)t * WL_STRIDE;
     const float sigma = (float)(L.sd * 7.071067812);                  // sift.c:1453
@@ -184,7 +187,8 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
                                                  const sift3d_hip_kp *__restrict__ kps, uint32_t first,
                                                  uint32_t n,
                                                  float *__restrict__ out, float *__restrict__ out2,
-                                                 const float *__restrict__ wlut DESC_ABLATE_ARG)
+                                                 const float *__restrict__ wlut,
+                                                 uint32_t *__restrict__ work DESC_ABLATE_ARG)
 {
     // per wave: 2 * 3200 + 2016 + 1024 B; per workgroup 39.4 KB -> four workgroups = 16 waves per CU
     __shared__ float hist_[DWAVES][2 * HIST_LDS];   // one private histogram per half-wave
@@ -208,12 +212,29 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         soct[threadIdx.x] = c_oct_face[threadIdx.x];
         sexp[threadIdx.x] = s3d_exp2_tab[threadIdx.x];
     }
+    __syncthreads();              // the only workgroup barrier: from here on the waves are independent
+    // Keypoints are handed out one at a time from a counter (`work`; list order = widest windows first): a
+    // wave that has finished its keypoint takes the next one.  With a fixed assignment of four keypoints to a
+    // workgroup the three faster waves idled until the slowest was done -- their slots and LDS are released
+    // per WORKGROUP -- which left ~15 % of the wave slots empty.  Every wave leaves the loop when the
+    // counter passes the end of the list.  (work == nullptr: one keypoint per wave, by position.)
+    for (bool first_pass = true;; first_pass = false) {
+    uint32_t ki;
+    if (work) {
+        uint32_t t = 0;
+        if (lane == 0)
+            t = atomicAdd(work, 1u);
+        ki = first + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    } else {
+        if (!first_pass)
+            break;
+        ki = first + blockIdx.x * DWAVES + wv;
+    }
+    if (ki >= n)
+        break;
     for (int i = lane; i < 2 * HIST_LDS; i += 64)
         hist[i] = 0.0f;
-    __syncthreads();              // the only workgroup barrier: from here on the waves are independent
-    const uint32_t ki = first + blockIdx.x * DWAVES + wv;
-    if (ki >= n)
-        return;
+    wave_sync();
     const sift3d_hip_kp K = kps[ki];
     const sift3d_hip_level L = levels[K.level];
     const uint32_t orow = K.row1 ? K.row1 - 1 : ki;   // output row (launch order may differ)
@@ -799,6 +820,8 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         if (out2)
             out2[(size_t)orow * 768 + i] = v;
     }
+    wave_sync();                  // (the histogram is cleared for the next keypoint behind these reads)
+    }
 }
 
 extern "C" {
@@ -940,11 +963,31 @@ __attribute__((visibility("default"))) unsigned long long sift3d_amd_diag_desc_v
 
 size_t sift3d_hip_describe_wlut_floats(int nlevels)
 {
-    return nlevels > 0 ? (size_t)nlevels * WL_STRIDE : 0;
+    return nlevels > 0 ? (size_t)nlevels * WL_STRIDE + WL_COUNTERS : 0;
+}
+
+// workgroups of a descriptor launch: every keypoint's wave when there is no work counter, else no more than
+// the device holds at once (four 39.6 KB workgroups per CU), each wave looping over the counter
+static unsigned describe_grid(uint32_t count, bool counted)
+{
+    const unsigned need = (count + DWAVES - 1) / DWAVES;
+    if (!counted)
+        return need;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus < 1)
+            cus = 256;
+    }
+    const unsigned cap = (unsigned)cus * 4u;
+    return need < cap ? need : cap;
 }
 
 // records [0, n_exact) take the reference-order kernel, [n_exact, n) the fast one
-static int describe_launch(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d_kp, uint32_t n,
+static int describe_launch(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp, uint32_t n,
                            uint32_t n_exact, float *d_hist, float *d_hist2, const float *d_wlut,
                            void *stream)
 {
@@ -958,16 +1001,19 @@ static int describe_launch(const sift3d_hip_level *d_levels, const sift3d_hip_kp
 #else
 #define DESC_ABLATE_PASS
 #endif
+    // (the work counters sit behind the weight tables and were zeroed by k_desc_wlut)
+    uint32_t *work = d_wlut ? reinterpret_cast<uint32_t *>(const_cast<float *>(d_wlut) + (size_t)nlevels * WL_STRIDE)
+                            : nullptr;
     if (n_exact) {
-        hipLaunchKernelGGL(k_describe<true>, dim3((n_exact + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
-                           (hipStream_t)stream, d_levels, d_kp, 0u, n_exact, d_hist, d_hist2,
-                           d_wlut DESC_ABLATE_PASS);
+        hipLaunchKernelGGL(k_describe<true>, dim3(describe_grid(n_exact, work != nullptr)), dim3(64 * DWAVES), 0,
+                           (hipStream_t)stream, d_levels, d_kp, 0u, n_exact, d_hist, d_hist2, d_wlut,
+                           work DESC_ABLATE_PASS);
         LAUNCH_CHECK();
     }
     if (n > n_exact) {
-        hipLaunchKernelGGL(k_describe<false>, dim3((n - n_exact + DWAVES - 1) / DWAVES), dim3(64 * DWAVES), 0,
-                           (hipStream_t)stream, d_levels, d_kp, n_exact, n, d_hist, d_hist2,
-                           d_wlut DESC_ABLATE_PASS);
+        hipLaunchKernelGGL(k_describe<false>, dim3(describe_grid(n - n_exact, work != nullptr)),
+                           dim3(64 * DWAVES), 0, (hipStream_t)stream, d_levels, d_kp, n_exact, n, d_hist,
+                           d_hist2, d_wlut, work ? work + 1 : nullptr DESC_ABLATE_PASS);
         LAUNCH_CHECK();
     }
 #undef DESC_ABLATE_PASS
@@ -979,7 +1025,7 @@ int sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d
 {
     if (!n)
         return SIFT3D_SUCCESS;
-    return describe_launch(d_levels, d_kp, n, 0, d_hist, nullptr, nullptr, stream);
+    return describe_launch(d_levels, 0, d_kp, n, 0, d_hist, nullptr, nullptr, stream);
 }
 
 int sift3d_hip_describe_ex(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
@@ -989,10 +1035,10 @@ int sift3d_hip_describe_ex(const sift3d_hip_level *d_levels, int nlevels, const 
     if (!n)
         return SIFT3D_SUCCESS;
     if (!d_wlut || nlevels < 1)
-        return describe_launch(d_levels, d_kp, n, n_exact, d_hist, d_hist2, nullptr, stream);
+        return describe_launch(d_levels, 0, d_kp, n, n_exact, d_hist, d_hist2, nullptr, stream);
     hipLaunchKernelGGL(k_desc_wlut, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, d_levels, nlevels,
                        d_wlut);
-    return describe_launch(d_levels, d_kp, n, n_exact, d_hist, d_hist2, d_wlut, stream);
+    return describe_launch(d_levels, nlevels, d_kp, n, n_exact, d_hist, d_hist2, d_wlut, stream);
 }
 
 int sift3d_hip_describe_wlut2(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
