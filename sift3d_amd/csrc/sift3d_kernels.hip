@@ -1495,7 +1495,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         return fmaxf(fmaxf(mm, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     };
     // differences 1..3 at planes z-1 (m), z (c), z+1 (p); Gaussian levels 1 and 4 at plane z
-    float4 m[3], c[3], p[3], hc[3], g1c, g4c;
+    float4 m[3], c[3], p[3], g1c, g4c;
     {
         float4 a[4], b[4];
 #pragma unroll
@@ -1510,9 +1510,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         g1c = b[0];
         g4c = b[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-            hc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (the halo rows' differences go straight into the tile the plane will use: the buffer of the NEXT
+        // plane was last read two planes ago, behind a barrier; nothing of them is carried in registers)
         if (halo) {
             float4 h[4];
 #pragma unroll
@@ -1520,8 +1519,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 h[k] = ld4(S.d[k + 1] + (size_t)p0 * zs + oh);
 #pragma unroll
             for (int i = 0; i < 3; i++)
-                hc[i] = sub4(h[i], h[i + 1]);
+                tile[0][i][hr * (TY + 1)][qx] = sub4(h[i], h[i + 1]);
         }
+    }
+    // The x neighbours of a row segment's two end quads come from memory (every other one from the adjacent
+    // lane): Gaussian levels 1..4 at x - 1 (lane qx == 0) or x + 4 (lane qx == TXQ - 1) of the centre plane.
+    // They are requested ONE PLANE AHEAD, like every other sample of the sweep: requested where they are
+    // needed, each of the six differences cost the wave a full memory round trip per plane -- s_waitcnt
+    // vmcnt(0) six times, draining the plane's 16-byte loads with it -- and every wave of a 256-voxel row
+    // segment holds both end lanes (measured: 6.8 us per plane and workgroup, 2.7 TB/s).
+    const bool edge = col && ((qx == 0 && x > 0) || (qx == TXQ - 1 && x + 4 < nx));
+    const size_t oe = oc + (qx == 0 ? (size_t)-1 : (size_t)4);
+    float ed[3] = { 0.f, 0.f, 0.f };          // centre plane's differences (beyond the volume: 0, as before)
+    if (edge) {
+        float e0[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            e0[k] = S.d[k + 1][(size_t)p0 * zs + oe];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            ed[i] = e0[i] - e0[i + 1];
     }
     int buf = 0;
 #pragma unroll 1
@@ -1529,11 +1546,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const size_t zo = (size_t)z * zs;
         // centre-plane differences into the tile (known since the previous step)
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < 3; i++)
             tile[buf][i][ty + 1][qx] = c[i];
-            if (halo)
-                tile[buf][i][hr * (TY + 1)][qx] = hc[i];
-        }
         // this step's loads: every Gaussian level once
         float4 n[4], hn[4];
 #pragma unroll
@@ -1545,19 +1559,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int k = 0; k < 4; k++)
                 hn[k] = ld4(S.d[k + 1] + zo + zs + oh);
         }
+        float en[4] = { 0.f, 0.f, 0.f, 0.f };     // the end quads' outer neighbours of the NEXT centre plane
+        if (edge) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                en[k] = S.d[k + 1][zo + zs + oe];
+        }
         float lf[3], rt[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            // x neighbours of the quad's ends: adjacent lanes of the 16-lane row, or memory at
-            // the ends of the 64-voxel tile
             // the neighbours come from the adjacent lanes of the WAVE (DPP wave shift; a wave holds
-            // 64 / TXQ whole row segments), memory only at the two ends of a row segment
+            // 64 / TXQ whole row segments), memory (ec, requested a plane ago) only at the two ends of a
+            // row segment
             lf[i] = __int_as_float(dpp_i<0x138>(__float_as_int(c[i].w)));   // wave_shr:1
             rt[i] = __int_as_float(dpp_i<0x130>(__float_as_int(c[i].x)));   // wave_shl:1
-            if (qx == 0)
-                lf[i] = col && x > 0 ? S.d[i + 1][zo + oc - 1] - S.d[i + 2][zo + oc - 1] : 0.0f;
-            if (qx == TXQ - 1)
-                rt[i] = col && x + 4 < nx ? S.d[i + 1][zo + oc + 4] - S.d[i + 2][zo + oc + 4] : 0.0f;
+            lf[i] = qx == 0 ? ed[i] : lf[i];
+            rt[i] = qx == TXQ - 1 ? ed[i] : rt[i];
         }
         __syncthreads();
         float4 up[3], dn[3];
@@ -1622,10 +1639,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         g1c = n[0];
         g4c = n[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            ed[i] = en[i] - en[i + 1];
         if (halo) {
 #pragma unroll
             for (int i = 0; i < 3; i++)
-                hc[i] = sub4(hn[i], hn[i + 1]);
+                tile[buf][i][hr * (TY + 1)][qx] = sub4(hn[i], hn[i + 1]);   // (buf: the next plane's)
         }
     }
     if (EST) {
