@@ -643,7 +643,7 @@ def main():
         if yz_in_step and min(yz_in_step) > 0:
             # (no microbench leg: the in-step launch of the dominant kernel, as the default run reports it)
             yz_ms = 1e3 * float(np.median(yz_in_step))
-            out["roofline"].update(dominant_kernel="k_fir_yz_u1<8, ...> (last blur of octave 0)",
+            out["roofline"].update(dominant_kernel="k_fir_yz_dma<8, 32> (last blur of octave 0)",
                                    dominant_avg_launch_ms=round(yz_ms, 4),
                                    dominant_frac=round(16.0 * n ** 3 / 1e9 / (yz_ms * 1e-3) / HBM_PEAK_GBS, 4))
     if not a.no_cpu and world == 1:          # the CPU leg runs at N = 1 only
