@@ -1203,6 +1203,23 @@ __global__ __launch_bounds__(256) void k_downsample2(const float *__restrict__ s
         src[(size_t)(2 * x) + (size_t)nx * ((size_t)(2 * y) + (size_t)ny * (2 * z))];
 }
 
+// the same for rows of whole quads on both sides (mx % 4 == 0, nx >= 2 mx, 16-byte aligned): a thread reads
+// two 16-byte quads and writes one; a workgroup covers 4 output rows of up to 256 voxels.  (One dword per
+// thread and 1 KB per workgroup made the first link of the smaller octaves' chain -- 512^3 -> 256^3 -- a
+// 65 536-workgroup launch.)
+__global__ __launch_bounds__(256) void k_downsample2_q(const float *__restrict__ src, int nx, int ny,
+                                                       float *__restrict__ dst, int mxq, int my, int mz)
+{
+    const int qx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int z = blockIdx.z;
+    if (qx >= mxq || y >= my)
+        return;
+    const float *s = src + (size_t)(8 * qx) + (size_t)nx * ((size_t)(2 * y) + (size_t)ny * (2 * z));
+    const float4 a = ld4(s), b = ld4(s + 4);
+    st4(dst + (size_t)(4 * qx) + (size_t)(4 * mxq) * ((size_t)y + (size_t)my * z), make_float4(a.x, a.z, b.x, b.z));
+}
+
 // ---------------------------------------------------------------------------------------
 // detect_extrema  (sift.c:735-871): mask -> scan -> emit, output in scan order
 // ---------------------------------------------------------------------------------------
@@ -3157,8 +3174,12 @@ int sift3d_hip_downsample2(const float *d_src, int nx, int ny, float *d_dst, int
 {
     if (mx < 1 || my < 1 || mz < 1)
         return SIFT3D_SUCCESS;
-    hipLaunchKernelGGL(k_downsample2, dim3((mx + 255) / 256, my, mz), dim3(256), 0,
-                       (hipStream_t)stream, d_src, nx, ny, d_dst, mx, my, mz);
+    if ((mx & 3) == 0 && (nx & 3) == 0 && nx >= 2 * mx && ((((uintptr_t)d_src | (uintptr_t)d_dst) & 15) == 0))
+        hipLaunchKernelGGL(k_downsample2_q, dim3((mx / 4 + 63) / 64, (my + 3) / 4, mz), dim3(256), 0,
+                           (hipStream_t)stream, d_src, nx, ny, d_dst, mx / 4, my, mz);
+    else
+        hipLaunchKernelGGL(k_downsample2, dim3((mx + 255) / 256, my, mz), dim3(256), 0,
+                           (hipStream_t)stream, d_src, nx, ny, d_dst, mx, my, mz);
     LAUNCH_CHECK();
     return SIFT3D_SUCCESS;
 }
