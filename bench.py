@@ -104,7 +104,7 @@ def kernel_microbench(torch, hip, n, reps=10):
         x_ms = [ev[3 * r].elapsed_time(ev[3 * r + 1]) for r in range(reps)]
         yz_ms = [ev[3 * r + 1].elapsed_time(ev[3 * r + 2]) for r in range(reps)]
         # (the launchers' choices: sift3d_kernels.hip launch_fir_x_u1, sift3d_fir_yz.hip launch_fir_yz)
-        row(("k_fir_x_u1f<%d, 0>" if n % 512 == 0 else "k_fir_x_u1<%d>") % hw, hw, 0, 8.0, x_ms, True)
+        row(("k_fir_x_u1f<%d, false>" if n % 512 == 0 else "k_fir_x_u1<%d>") % hw, hw, 0, 8.0, x_ms, True)
         if n % 64 == 0 and n >= 128:
             yzname = "k_fir_yz_dma<%d, %d>" % (hw, 64 if hw <= 2 else 32)
         else:
