@@ -260,7 +260,8 @@ SIFT3D_AMD_API int sift3d_amd_sharded_describe(sift3d_amd_sharded *, const sift3
  * (sift3d_amd_sharded_describe: desc_own / own_idx / n_own of THIS rank): one all-gather of the ranks' row
  * blocks, device to device.  root < 0: `all` is filled on every rank; else on rank `root` only (the others
  * take part in the exchange and leave `all` alone).  Collective; the status word behind every block makes a
- * rank-local failure return SIFT3D_FAILURE on every rank. */
+ * rank-local failure return SIFT3D_FAILURE on every rank -- a rank whose sift3d_amd_sharded_describe failed
+ * still calls this, with n_own = -1. */
 SIFT3D_AMD_API int
 sift3d_amd_sharded_gather_descriptors(sift3d_amd_sharded *, const sift3d_keypoint_store *kp,
                                       const sift3d_descriptor_store *desc_own, const int *own_idx, int n_own,

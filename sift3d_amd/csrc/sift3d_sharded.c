@@ -1236,19 +1236,22 @@ int sift3d_amd_sharded_gather_descriptors(sift3d_amd_sharded *S, const sift3d_ke
     map = (uint32_t *)malloc(sizeof(uint32_t) * (num ? num : 1));
     if (!map)
         failed = failed ? failed : __LINE__;
-    for (q = 0; q < num && map; q++) {
+    /* (the counts size the exchange: every rank must arrive at the same ones, whatever failed locally) */
+    for (q = 0; q < num; q++) {
         const keypoint_t *k = kp->buf + q;
         int rr = 0;
         if (k->o < 0 || k->o >= S->num_octaves) {
-            failed = failed ? failed : __LINE__;
-            map[q] = 0;
+            failed = failed ? failed : __LINE__;       /* (the list is the same on every rank) */
+            if (map)
+                map[q] = 0;
             continue;
         }
         if (W > 1)
             for (rr = 0; rr < W - 1; rr++)
                 if (k->zd < (double)S->bounds[k->o][rr + 1])
                     break;
-        map[q] = ((uint32_t)rr << 24) | (uint32_t)(cnt[rr] & 0xffffffu);
+        if (map)
+            map[q] = ((uint32_t)rr << 24) | (uint32_t)(cnt[rr] & 0xffffffu);
         cnt[rr]++;
     }
     for (r = 0; r < W; r++)
@@ -1289,6 +1292,8 @@ int sift3d_amd_sharded_gather_descriptors(sift3d_amd_sharded *S, const sift3d_ke
         free(map);
         return SIFT3D_FAILURE;                         /* on every rank, here */
     }
+    if (want && !map)
+        return SIFT3D_FAILURE;                         /* (unreachable: a missing map was reported above) */
     if (want) {
         /* rows into the global order on the device, one copy into the store's page-locked array */
         const size_t cap = num + num / 8 + 64;
