@@ -312,6 +312,15 @@ def test_detect_describe_golden(gpu, oracle_mod, name):
     if name in ("g3_sigma3", "g3_sigma5"):
         # windows of 2e5 .. 4e6 voxels: the automatic mode has taken the reference-order kernel for them
         np.testing.assert_array_equal(m, m2)
+        # ... because the fast commit (another summation order; here also the weights computed per voxel, not
+        # tabulated) drifts with the square root of the terms a bin receives: the difference to the
+        # reference's own sequential float sums reaches 1e-5 at sigma0 = 5 (measured 1.03e-5; bar here 3e-5)
+        assert det.set_exact_descriptors(-1) == 0
+        desc3 = api.DescriptorStore()
+        assert det.extract_descriptors(kp, desc3) == 0
+        e = util.rel_err(desc3.to_mat_rm()[idx, 3:], g["desc_hist"])
+        print("%s: fast commit, max elementwise relative difference to the reference %.3g" % (name, e))
+        assert 0.0 < e <= 3e-5
     for lim in (0, 10):
         det2, kp2, rc = _run_api(api, vol, tuple(g["units"]), params)
         kp2.sort_by_strength(lim)
