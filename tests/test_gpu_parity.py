@@ -116,7 +116,10 @@ def test_fir_golden(gpu, variant):
 
 
 @pytest.mark.parametrize("shape", [(40, 36, 128), (33, 30, 516), (16, 24, 64), (19, 21, 23),
-                                   (70, 64, 64)])
+                                   (70, 64, 64),
+                                   # rows of whole 512-float segments (k_fir_x_u1f: two rows in flight): a last
+                                   # wave with fewer than its eight rows, two segments per row
+                                   (5, 7, 512), (3, 9, 1024)])
 def test_fir_fast_paths_vs_oracle(gpu, oracle_mod, shape):
     """All specialised kernels (x register-window, y/z register-ring, dyadic tables) on
     shapes that exercise vector / scalar paths, partial segments and short axes."""
@@ -168,7 +171,10 @@ def test_fir_slab_z(gpu, oracle_mod):
 
 
 @pytest.mark.parametrize("shape", [(40, 48, 64), (70, 33, 128), (24, 100, 20), (36, 80, 256), (22, 150, 128),
-                                   (30, 128, 64)])
+                                   (30, 128, 64),
+                                   # whole 64 x 64 / 64 x 32 tiles (k_fir_yz_dma: rows by LDS-DMA): several tile
+                                   # rows incl. the one with the virtual rows, more planes than one request list
+                                   (20, 192, 128), (300, 128, 64)])
 def test_fir_fused_yz_vs_oracle(gpu, oracle_mod, shape):
     """Fused y+z kernel == FIR_z(FIR_y(.)) of the oracle, whole volume and as Z-slabs (partial
     tiles in x and y, both global z faces, interior slab faces)."""
