@@ -1572,6 +1572,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
         const int s_end = d->ngl - 2;
         const int ds = s_end - 2 > -1 ? s_end - 2 : -1;
         const int forked = d->num_octaves > 1 && d->num_octaves <= 32 && ds + 1 < d->ngl - 1;
+        int o0_rest = 0;         /* first level of octave 0 that is still to be enqueued (0: none) */
         for (o = 0; o < d->num_octaves; o++) {
             double lu[3];
             void *st = (o > 0 && forked) ? d->oct_stream : d->stream;
@@ -1591,10 +1592,18 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                                            d->d_g[d->ngl], d->odims[1][0], d->odims[1][1], d->odims[1][2],
                                            d->oct_stream))
                     return SIFT3D_FAILURE;
-                for (; s < d->ngl; s++)
-                    if (blur_level(d, d->d_g[s - 1], d->d_g[s], d->odims[0], lu, &d->filt[s], d->stream,
-                                   d->d_tmp_a, d->d_tmp_b, s == d->ngl - 1, NULL))
-                        return SIFT3D_FAILURE;
+                /* The last levels of octave 0 are held back until octave 1 has reached ITS source level.  The
+                 * fused y+z kernel keeps one or two workgroups on every CU for its whole duration: beside it
+                 * the passes of octave 1 -- which the whole chain of smaller octaves waits for -- get what
+                 * registers and LDS it leaves (in the step 2-7x their stand-alone time), and it loses
+                 * bandwidth to them.  Octave 1's first levels alone take 0.4 ms; the pyramid's total does
+                 * not change (3.39-3.52 against 3.51 ms), the two large kernels' interference does. */
+                o0_rest = s;
+                if (d->num_octaves < 2)
+                    for (; s < d->ngl; s++)
+                        if (blur_level(d, d->d_g[s - 1], d->d_g[s], d->odims[0], lu, &d->filt[s], d->stream,
+                                       d->d_tmp_a, d->d_tmp_b, s == d->ngl - 1, NULL))
+                            return SIFT3D_FAILURE;
                 continue;
             }
             for (s = 1; s < d->ngl; s++) {
@@ -1608,6 +1617,19 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                                                d->d_g[(o + 1) * d->ngl], d->odims[o + 1][0],
                                                d->odims[o + 1][1], d->odims[o + 1][2], st))
                         return SIFT3D_FAILURE;
+                    if (o0_rest) {
+                        /* ... and now octave 0's last levels, on the main stream */
+                        double lu0[3];
+                        int s0;
+                        level_units(d, 0, lu0);
+                        if (sift3d_hip_stream_wait_event(d->stream, d->ev_oct[o]))
+                            return SIFT3D_FAILURE;
+                        for (s0 = o0_rest; s0 < d->ngl; s0++)
+                            if (blur_level(d, d->d_g[s0 - 1], d->d_g[s0], d->odims[0], lu0, &d->filt[s0],
+                                           d->stream, d->d_tmp_a, d->d_tmp_b, s0 == d->ngl - 1, NULL))
+                                return SIFT3D_FAILURE;
+                        o0_rest = 0;
+                    }
                     st = d->side_stream;
                     ta = d->d_tmp3_a;
                     tb = d->d_tmp3_b;
@@ -1704,11 +1726,16 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
         if (side) {
             /* the sweeps side by side, then scan + emission in octave order */
             int phase;
+            /* three chains: octave 0 | octaves 1, 2 | the small octaves, whose 4-40 us launches (four per
+             * octave, each waiting for its predecessor) otherwise queue behind octave 1's sweep and end the
+             * stage 0.1 ms after octave 0 has finished */
             if (sift3d_hip_event_record(d->ev_fork, d->stream) ||
-                sift3d_hip_stream_wait_event(d->oct_stream, d->ev_fork))
+                sift3d_hip_stream_wait_event(d->oct_stream, d->ev_fork) ||
+                sift3d_hip_stream_wait_event(d->side_stream, d->ev_fork))
                 return SIFT3D_FAILURE;
             for (phase = 1; phase <= 2; phase++) {
                 for (o = 0; o < d->num_octaves; o++) {
+                    void *const xs = phase != 1 || o == 0 ? d->stream : o <= 2 ? d->oct_stream : d->side_stream;
                     void *wk = o ? (void *)((char *)d->d_work2 + d->work2_off[o]) : d->d_work;
                     const size_t wb = o ? sift3d_hip_extrema_work_bytes(d->odims[o][0], d->odims[o][1],
                                                                         d->odims[o][2], 3)
@@ -1719,8 +1746,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                                 d->d_scalars + 8 + (d->num_octaves + o) * d->ndl,
                                 d->d_scalars + 8 + o * d->ndl, d->odims[o][0], d->odims[o][1],
                                 d->odims[o][2], o * d->ngl + 1, d->peak_thresh, d->d_cand, d->cand_cap,
-                                (uint32_t *)(d->d_scalars + 1), wk, wb,
-                                phase == 1 && o > 0 ? d->oct_stream : d->stream, phase))
+                                (uint32_t *)(d->d_scalars + 1), wk, wb, xs, phase))
                             return SIFT3D_FAILURE;
                         continue;
                     }
@@ -1728,12 +1754,13 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                             (const float *const *)(d->d_g + o * d->ngl), d->d_scalars + 8 + o * d->ndl,
                             d->odims[o][0], d->odims[o][1], d->odims[o][2], 1, d->odims[o][2] - 1,
                             o * d->ngl + 1, d->peak_thresh, d->d_cand, d->cand_cap,
-                            (uint32_t *)(d->d_scalars + 1), wk, wb,
-                            phase == 1 && o > 0 ? d->oct_stream : d->stream, phase))
+                            (uint32_t *)(d->d_scalars + 1), wk, wb, xs, phase))
                         return SIFT3D_FAILURE;   /* (coverage was established by the dogmax calls) */
                 }
                 if (phase == 1 && (sift3d_hip_event_record(d->ev_join, d->oct_stream) ||
-                                   sift3d_hip_stream_wait_event(d->stream, d->ev_join)))
+                                   sift3d_hip_stream_wait_event(d->stream, d->ev_join) ||
+                                   sift3d_hip_event_record(d->ev_join2, d->side_stream) ||
+                                   sift3d_hip_stream_wait_event(d->stream, d->ev_join2)))
                     return SIFT3D_FAILURE;
             }
         }
