@@ -2560,24 +2560,34 @@ __global__ __launch_bounds__(64 * ORI_CPW) void k_orient_sums(const sift3d_hip_l
     };
     const f4v zero4 = { 0.f, 0.f, 0.f, 0.f };
     if (interior) {
-        // One chunk of 64 quads per iteration, its table entries requested one iteration ahead (the
-        // sample addresses come out of the entries: without the lookahead every chunk would expose two
-        // dependent memory round trips).  Measured 1.89 / 1.96 / 1.98 / 2.05 ms for 1 / 2 / 3 / 4 chunks per
+        // One chunk of 64 quads per iteration, the next chunk's quad offset requested one iteration ahead
+        // (the sample addresses come out of it: without the lookahead every chunk would expose two dependent
+        // memory round trips).  What bounds the kernel are the sample loads themselves (1.47 of its 1.49 ms
+        // with the arithmetic compiled out, 0.74 ms for the arithmetic alone).  Measured 1.89 / 1.96 / 1.98 / 2.05 ms for 1 / 2 / 3 / 4 chunks per
         // iteration: more chunks in flight per wave cost registers, i.e. waves (5 per SIMD at 92 VGPRs;
         // forcing 6-8 waves per SIMD spills: 2.03 / 2.28 / 3.2 ms; a lean launch for the unclipped windows
         // alone fits 6 waves and gains nothing).  Idle lanes repeat the last quad with weight 0.
         const uint32_t last = count - 1;
         auto slot = [&](uint32_t t0) -> uint32_t { return min(t0 + (uint32_t)lane, last); };
-        u2v mc = meta[slot(0)];
-        f4v wc = wts[slot(0)];
+        // (Written as plain loads the compiler rotates the loop and uses an entry right after requesting
+        // it.  The OFFSET of the next chunk's quad -- all the sample addresses need -- is therefore requested
+        // by an instruction the compiler cannot move, and awaited at the end of the iteration; the loads it
+        // knows nothing about only make its own s_waitcnt counts conservative.  The weights do not feed an
+        // address: they travel with the samples.  `on` starts as a copy of the current offset, so a read
+        // before the wait could only repeat a valid address.)
+        typedef const uint32_t __attribute__((address_space(1))) *gu32_p;
+        const gu32_p moff = (gu32_p) reinterpret_cast<const uint32_t *>(tab + ORI_TAB_HEAD) + 1;   // meta[i].y
+        uint32_t oc = moff[2 * slot(0)];
         for (uint32_t t0 = 0; t0 < count; t0 += 64) {
-            const u2v mn = meta[slot(t0 + 64)];            // next iteration's entries
-            const f4v wn = wts[slot(t0 + 64)];
+            uint32_t on = oc;
+            const gu32_p pn = moff + 2 * slot(t0 + 64);
+            asm volatile("global_load_dword %0, %1, off" : "+v"(on) : "v"(pn));
+            const f4v wc = wts[slot(t0)];
             Quad q;
-            load_quad(centre + (int)mc.y, q);
+            load_quad(centre + (int)oc, q);
             sum_quad(q, t0 + (uint32_t)lane < count ? wc : zero4);
-            mc = mn;
-            wc = wn;
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(on));
+            oc = on;
         }
         nvox = (double)head[7];
     } else {
