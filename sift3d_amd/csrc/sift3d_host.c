@@ -1597,13 +1597,8 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                  * the passes of octave 1 -- which the whole chain of smaller octaves waits for -- get what
                  * registers and LDS it leaves (in the step 2-7x their stand-alone time), and it loses
                  * bandwidth to them.  Octave 1's first levels alone take 0.4 ms; the pyramid's total does
-                 * not change (3.39-3.52 against 3.51 ms), the two large kernels' interference does. */
-                o0_rest = s;
-                if (d->num_octaves < 2)
-                    for (; s < d->ngl; s++)
-                        if (blur_level(d, d->d_g[s - 1], d->d_g[s], d->odims[0], lu, &d->filt[s], d->stream,
-                                       d->d_tmp_a, d->d_tmp_b, s == d->ngl - 1, NULL))
-                            return SIFT3D_FAILURE;
+                 * not change (3.47-3.51 against 3.48-3.49 ms), the two large kernels' interference does. */
+                o0_rest = s;     /* (forked: octave 1 exists and reaches the point where they are enqueued) */
                 continue;
             }
             for (s = 1; s < d->ngl; s++) {
