@@ -174,7 +174,9 @@ def test_fir_slab_z(gpu, oracle_mod):
                                    (30, 128, 64),
                                    # whole 64 x 64 / 64 x 32 tiles (k_fir_yz_dma: rows by LDS-DMA): several tile
                                    # rows incl. the one with the virtual rows, more planes than one request list
-                                   (20, 192, 128), (300, 128, 64)])
+                                   (20, 192, 128), (300, 128, 64),
+                                   # ... and the fewest planes the fused kernel accepts for 17 taps (2 hw + 2)
+                                   (18, 128, 64), (19, 256, 192)])
 def test_fir_fused_yz_vs_oracle(gpu, oracle_mod, shape):
     """Fused y+z kernel == FIR_z(FIR_y(.)) of the oracle, whole volume and as Z-slabs (partial
     tiles in x and y, both global z faces, interior slab faces)."""
