@@ -138,6 +138,20 @@ def test_fir_fast_paths_vs_oracle(gpu, oracle_mod, shape):
                                               % (sigma, uf, ax))
 
 
+@pytest.mark.parametrize("shape", [(1, 1, 512), (1, 3, 1024), (2, 2, 512), (1, 17, 1536)])
+def test_fir_x_few_rows(gpu, oracle_mod, shape):
+    """The x pass with whole 512-float segments (k_fir_x_u1f) on volumes with fewer rows than one wave takes."""
+    api, hip, torch = gpu
+    rng = np.random.default_rng(sum(shape))
+    vol = rng.standard_normal(shape).astype(np.float32)
+    for sigma in (0.5387011637869722, 1.2262734984654078, 2.4525469969308156):
+        taps = oracle_mod.gauss_taps(sigma)
+        want, r = oracle_mod.fir_axis(vol, taps, 0, uf=np.float32(1.0), mode=0)
+        assert r == 0
+        got = _fir_gpu(hip, torch, vol, taps, 0, np.float32(1.0))
+        np.testing.assert_array_equal(got, want, err_msg="sigma %g" % sigma)
+
+
 def test_fir_non_dyadic_literal(gpu, oracle_mod):
     """Anisotropic units give non-dyadic unit factors: the literal kernel with the
     reference's coordinate round trip (imutil.c:811-817)."""
