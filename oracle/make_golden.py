@@ -327,6 +327,22 @@ def main():
             "g3_sigma5", so.synth_survey(96), store_levels=False,
             params=dict(sigma0=5.0, peak_thresh=0.02, corner_thresh=0.2),
             input_spec=dict(gen="survey", n=96))
+    # Round 5: the descriptor kernel's fast / reference-order switch (sift3d_host.c exact_desc_first_level:
+    # windows of more than 1.9e5 voxels take the reference-order kernel).  sigma0 = 2.85: the keypoints of
+    # level s = 0 have windows of 1.85e5 voxels -- the LARGEST the fast commit is ever used for --, those of
+    # s = 1, 2 take the reference-order kernel.  Anisotropic units (1, 0.8, 0.8) at the default sigma0: the
+    # unit product 0.64 pushes the windows of s = 2 (1.31e5 / 0.64 = 2.05e5 voxels) over the switch, s = 0, 1
+    # stay below (sift.c:1453-1456, window radius in voxels = rad / unit: sift.c:96-108)
+    if a.only and "g3_switch" in a.only.split(","):
+        jobs["g3_switch"] = lambda: end_to_end(
+            "g3_switch285", so.synth_lattice(96, seed=17), store_levels=False,
+            params=dict(sigma0=2.85, peak_thresh=0.03, corner_thresh=0.3),
+            input_spec=dict(gen="lattice", n=96, seed=17))
+    if a.only and "g3_switch_aniso" in a.only.split(","):
+        jobs["g3_switch_aniso"] = lambda: end_to_end(
+            "g3_switch_aniso", so.synth_lattice((80, 112, 112), seed=19), units=(1.0, 0.8, 0.8),
+            store_levels=False, params=dict(peak_thresh=0.05, corner_thresh=0.3),
+            input_spec=dict(gen="lattice", n=[80, 112, 112], seed=19))
     if a.only and "g5_slab8" in a.only.split(","):
         # BASELINE configs[3]'s slab geometry at 1/16 of its voxels: 256 x 256 x 1024 (eight 128-plane
         # Z-slabs, o_shard = 2) -- the sharded GPU tests compare with THIS, not with the single-GPU API

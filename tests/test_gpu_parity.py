@@ -280,7 +280,7 @@ def _run_api(api, vol, units=(1, 1, 1), params=None, device_input=False):
 
 @pytest.mark.parametrize("name", ["g3_64", "g3_70x50x41", "g3_aniso", "g3_params",
                                   "g3_lattice48", "g5_128", "g3_cuboid64", "g3_cuboid_params",
-                                  "g3_sigma3", "g3_sigma5"])
+                                  "g3_sigma3", "g3_sigma5", "g3_switch285", "g3_switch_aniso"])
 def test_detect_describe_golden(gpu, oracle_mod, name):
     """Against the reference's own outputs: every pyramid level (sha1 digests + small levels
     in full), candidate count, the keypoint list incl. the stale-strength quirk, R,
@@ -343,6 +343,28 @@ def test_detect_describe_golden(gpu, oracle_mod, name):
         e = util.rel_err(desc3.to_mat_rm()[idx, 3:], g["desc_hist"])
         print("%s: fast commit, max elementwise relative difference to the reference %.3g" % (name, e))
         assert 0.0 < e <= 3e-5
+    if name in ("g3_switch285", "g3_switch_aniso"):
+        # Fixtures AT the fast / reference-order switch (sift3d_host.c exact_desc_first_level: windows of more
+        # than 1.9e5 voxels take the reference-order kernel).  g3_switch285 (sigma0 2.85): level s = 0 has
+        # windows of 1.85e5 voxels -- the largest the fast commit is ever used for --, s = 1, 2 switch;
+        # g3_switch_aniso (default sigma0, units 1 x 0.8 x 0.8): only s = 2 (2.05e5 voxels) switches.
+        first_exact = 1 if name == "g3_switch285" else 2
+        assert det.set_exact_descriptors(-1) == 0
+        desc3 = api.DescriptorStore()
+        assert det.extract_descriptors(kp, desc3) == 0
+        m3 = desc3.to_mat_rm()
+        slow = k["s"] >= first_exact
+        assert slow.any() and (~slow).any()
+        # the automatic mode switched exactly where the code says: rows above the switch are the reference-order
+        # kernel's (= the reference's, bit for bit), rows below it the fast commit's
+        np.testing.assert_array_equal(m[slow], m2[slow])
+        np.testing.assert_array_equal(m[~slow], m3[~slow])
+        assert not np.array_equal(m3[slow], m2[slow])
+        sel = ~slow[idx]
+        e = util.rel_err(m3[idx, 3:][sel], g["desc_hist"][sel])
+        print("%s: fast commit just below the switch, max elementwise relative difference to the reference %.3g"
+              % (name, e))
+        assert 0.0 < e <= RTOL
     for lim in (0, 10):
         det2, kp2, rc = _run_api(api, vol, tuple(g["units"]), params)
         kp2.sort_by_strength(lim)
