@@ -332,6 +332,38 @@ def launch_ranks(n):
     return rc
 
 
+# candidate -> keypoint counts of the bench workloads (lattice volume, seed 11, default parameters), as the
+# reference (512^3: tests/golden/g5_512.npz) and the single-GPU path / the 8-rank rehearsals of rounds 3-4
+# (profiles/r04_rehearsal_8ranks_weak.json, r04_rehearsal_8ranks_1024.json) produced them.  Every run checks
+# its own counts against these and exits non-zero on a mismatch: the first multi-GPU run verifies itself.
+KNOWN_COUNTS = {
+    ("weak", 512, 1): (158924, 42501), ("weak", 512, 2): (316228, 84538),
+    ("weak", 512, 4): (619908, 166329), ("weak", 512, 8): (1222989, 328589),
+}
+KNOWN_STRONG = {1024: (1249357, 332413), 512: (158924, 42501)}
+
+
+def expected_counts(strong, n, ranks):
+    return KNOWN_STRONG.get(n) if strong else KNOWN_COUNTS.get(("weak", n, ranks))
+
+
+def fir_kernel_names(api, n):
+    """(x kernel, y+z kernel, half width) of every octave-0 blur, as the launchers choose them
+    (sift3d_kernels.hip launch_fir_x_u1, sift3d_fir_yz.hip launch_fir_yz) -- blur 0 scales on the fly."""
+    sig = [0.5387011637869722, 0.9732939207323564, 1.2262734984654078, 1.5450077936447955,
+           1.9465878414647133, 2.4525469969308156]
+    out = []
+    for b, s in enumerate(sig):
+        hw = len(api.gauss_filter(s)) // 2
+        xk = ("k_fir_x_u1f<%d, %s>" % (hw, "true" if b == 0 else "false")) if n % 512 == 0 else "k_fir_x_u1<%d>" % hw
+        if n % 64 == 0 and n >= 128:
+            yk = "k_fir_yz_dma<%d, %d>" % (hw, 64 if hw <= 2 else 32)
+        else:
+            yk = "k_fir_yz_u1<%d, %s>" % (hw, "32, 32" if n % 128 == 0 else "32, 16")
+        out.append((xk, yk, hw))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -341,8 +373,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-micro", action="store_true", help="skip the per-kernel microbench")
     ap.add_argument("--strong", type=int, default=0, metavar="EDGE",
-                    help="strong scaling: ONE EDGE^3 volume (BASELINE configs[3]: 1024) cut into "
-                         "--gpus Z-slabs, instead of the default 512 planes per GPU")
+                    help="strong scaling as the MAIN line: ONE EDGE^3 volume (BASELINE configs[3]: 1024) cut "
+                         "into --gpus Z-slabs, instead of the default 512 planes per GPU")
+    ap.add_argument("--no-strong-leg", action="store_true",
+                    help="skip the strong_1024 sub-record (BASELINE configs[3]: one 1024^3 volume as N Z-slabs) "
+                         "that every default run carries beside its main line")
     ap.add_argument("--no-host", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
     ap.add_argument("--rehearse-threads", type=int, default=0, metavar="R",
                     help="N=1 only: R slab drivers as R threads of this process on the one device "
@@ -385,115 +420,180 @@ def main():
         # communicator (sift3d_amd_rccl_transport); no second RCCL communicator exists in the process.
         dist.init_process_group("gloo")
 
-    n = a.strong if a.strong else a.size
-    nz_total = n if a.strong else n * world
     if a.register:
         return register_bench(a, torch, api, hip)
     rt = a.rehearse_threads if world == 1 else 0
-    if rt > 1:
-        # R ranks as R threads: R C slab drivers on this device, exchanging through ThreadTransport
-        import threading
+    ranks = rt if rt > 1 else world
+
+    # one transport for every leg of the run (the library's RCCL communicator is opened once)
+    tr = None
+    if world > 1:
         from sift3d_amd import sharded_c
-        nz_total = n if a.strong else n * rt
-        grp = sharded_c.StreamThreadGroup(rt)      # stream-ordered exchanges (events only), as over RCCL
-        jobs = [None] * rt
+        tr = sharded_c.DistTransport() if rehearse else sharded_c.RcclTransport()
 
-        def _threads(fn):
-            err = []
+    def run_leg(n, nz_total, steps, warmup, use_api):
+        """K timed steps of one workload (barrier + synchronize on both sides, max over ranks).  Returns a dict:
+        seconds per step, stats, the pyramid's device seconds per step, octave 0's in-step launch timings."""
+        leg = {}
+        if rt > 1:
+            import threading
+            from sift3d_amd import sharded_c
+            grp = sharded_c.StreamThreadGroup(rt)      # stream-ordered exchanges (events only), as over RCCL
+            jobs = [None] * rt
+            trs = [None] * rt
 
-            def run(r):
-                try:
-                    fn(r)
-                except Exception as e:  # noqa: BLE001
-                    err.append((r, repr(e)))
-                    grp.barrier.abort()
-            th = [threading.Thread(target=run, args=(r,)) for r in range(rt)]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            if err:
-                raise SystemExit("rehearsal failed: %s" % err)
+            def _threads(fn):
+                err = []
 
-        def _make(r):
-            jobs[r] = sharded_c.CShardedSift3D(n, n, nz_total, sharded_c.StreamThreadTransport(grp, r))
-            jobs[r].synth(seed=11)
-        _threads(_make)
-        step = lambda: _threads(lambda r: jobs[r].step())  # noqa: E731
-        stats = lambda: dict(jobs[0].stats(), rehearsal="%d ranks as threads of one process on one device: "  # noqa: E731
-                             "code path and geometry of N = %d, not a scaling measurement" % (rt, rt),
-                             per_rank_max_s={k: round(max(j.breakdown()[k] for j in jobs), 6)
-                                             for k in jobs[0].breakdown()})
-        pyr_time = jobs[0].pyramid_seconds
-    elif world == 1 and not a.sharded:
-        vol = torch.empty((n, n, n), device="cuda")
-        hip.synth_lattice(vol, 0, 11)
-        torch.cuda.synchronize()
-        det = api.Detector()
-        kp, desc = api.KeypointStore(), api.DescriptorStore()
+                def run(r):
+                    try:
+                        fn(r)
+                    except Exception as e:  # noqa: BLE001
+                        err.append((r, repr(e)))
+                        grp.barrier.abort()
+                th = [threading.Thread(target=run, args=(r,)) for r in range(rt)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                if err:
+                    raise SystemExit("rehearsal failed: %s" % err)
 
-        def step():
-            rc = det.detect_keypoints_device(vol.data_ptr(), n, n, n, kp)
-            assert rc == 0, "detect failed"
-            rc = det.extract_descriptors(kp, desc)
-            assert rc == 0, "describe failed"
+            def _make(r):
+                trs[r] = sharded_c.StreamThreadTransport(grp, r)
+                jobs[r] = sharded_c.CShardedSift3D(n, n, nz_total, trs[r])
+                jobs[r].synth(seed=11)
+            _threads(_make)
+            step = lambda: _threads(lambda r: jobs[r].step())  # noqa: E731
+            stats = lambda: dict(jobs[0].stats(), rehearsal="%d ranks as threads of one process on one device: "  # noqa: E731
+                                 "code path and geometry of N = %d, not a scaling measurement" % (rt, rt),
+                                 per_rank_max_s={k: round(max(j.breakdown()[k] for j in jobs), 6)
+                                                 for k in jobs[0].breakdown()})
+            pyr_time = jobs[0].pyramid_seconds
+            closer = lambda: ([j.close() for j in jobs], [t.close() for t in trs], grp.close())  # noqa: E731
+            job = None
+        elif use_api:
+            vol = torch.empty((nz_total, n, n), device="cuda")
+            hip.synth_lattice(vol, 0, 11)
+            torch.cuda.synchronize()
+            det = api.Detector()
+            kp, desc = api.KeypointStore(), api.DescriptorStore()
 
-        stats = lambda: dict(candidates=det.num_candidates(), keypoints=len(kp),  # noqa: E731
-                             stage_s={k: round(v, 6) for k, v in det.timings().items()})
-        pyr_time = lambda: (lambda t: (t["gauss_dev"], t.get("yz_last", 0.0)))(det.timings())  # noqa: E731
-    else:
-        # The slab driver in C (sift3d_amd/csrc/sift3d_sharded.c) over the library's own RCCL
-        # communicator; rehearsals on one device stage the exchanges through gloo.
-        from sift3d_amd import sharded_c
-        if world == 1:
-            tr = None
-        elif rehearse:
-            tr = sharded_c.DistTransport()
+            def step():
+                rc = det.detect_keypoints_device(vol.data_ptr(), n, n, nz_total, kp)
+                assert rc == 0, "detect failed"
+                rc = det.extract_descriptors(kp, desc)
+                assert rc == 0, "describe failed"
+
+            stats = lambda: dict(candidates=det.num_candidates(), keypoints=len(kp),  # noqa: E731
+                                 stage_s={k: round(v, 6) for k, v in det.timings().items()})
+            pyr_time = lambda: det.timings()["gauss_dev"]  # noqa: E731
+            leg.update(det=det, kp=kp, desc=desc, vol=vol)
+            closer = lambda: None  # noqa: E731
+            job = None
         else:
-            tr = sharded_c.RcclTransport()
-        job = sharded_c.CShardedSift3D(n, n, nz_total, tr)
-        job.synth(seed=11)
-        step = job.step
-        stats = job.stats
-        pyr_time = job.pyramid_seconds
-    voxels_per_step = n * n * nz_total
-
-    for _ in range(a.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pyr, yz_in_step = [], []
-    for _ in range(a.steps):
-        step()
-        pt_ = pyr_time()
-        if isinstance(pt_, tuple):
-            pyr.append(pt_[0])
-            yz_in_step.append(pt_[1])
-        else:
-            pyr.append(pt_)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    per_rank = None
-    if world > 1 and hasattr(job, "breakdown"):
-        # stage seconds of the last step, max over ranks (so that a scaling curve can be read)
-        bd = job.breakdown()
-        keys = sorted(bd)
-        t = torch.tensor([bd[k] for k in keys], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        per_rank = {k: round(float(v), 6) for k, v in zip(keys, t.tolist())}
-    def _finish():
-        """Tear the ranks down in step: slab driver, the library's RCCL communicator, the process group."""
+            # The slab driver in C (sift3d_amd/csrc/sift3d_sharded.c) over the library's own RCCL
+            # communicator; rehearsals on one device stage the exchanges through gloo.
+            from sift3d_amd import sharded_c
+            job = sharded_c.CShardedSift3D(n, n, nz_total, tr)
+            job.synth(seed=11)
+            step = job.step
+            stats = job.stats
+            pyr_time = job.pyramid_seconds
+            closer = job.close
+        for _ in range(warmup):
+            step()
         if world > 1:
-            job.close()
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pyr, launches, dclk = [], [], []
+        for _ in range(steps):
+            step()
+            pyr.append(pyr_time())
+            if "det" in leg:
+                launches.append(leg["det"].launch_timings())
+                dclk.append(leg["det"].describe_clock())
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        per_rank = None
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            if job is not None:
+                # stage seconds of the last step, max over ranks (so that a scaling curve can be read)
+                bd = job.breakdown()
+                keys = sorted(bd)
+                t = torch.tensor([bd[k] for k in keys] + [float(np.median(pyr))], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                per_rank = {k: round(float(v), 6) for k, v in zip(keys, t.tolist())}
+                pyr = [float(t[-1])]                 # the slowest rank's pyramid
+        leg.update(sec_per_step=dt / steps, stats=stats(), pyr=pyr, launches=launches, dclk=dclk,
+                   per_rank=per_rank, close=closer, voxels=n * n * nz_total)
+        return leg
+
+    def pyramid_record(n, nz_rank, seconds):
+        pbytes = pyramid_algorithmic_bytes(n, n, nz_rank)
+        ach = pbytes / 1e9 / seconds
+        return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_GB": round(pbytes / 1e9, 3),
+                "seconds": round(seconds, 6)}
+
+    n = a.strong if a.strong else a.size
+    nz_total = n if a.strong else n * ranks
+    use_api = world == 1 and not a.sharded and not rt
+    main_leg = run_leg(n, nz_total, a.steps, a.warmup, use_api)
+    failed = []
+
+    def check(tag, strong, edge, st):
+        want = expected_counts(strong, edge, ranks)
+        got = (int(st["candidates"]), int(st["keypoints"]))
+        if want is None:
+            return None
+        if got != want:
+            failed.append("%s: %d candidates -> %d keypoints, expected %d -> %d" % ((tag,) + got + want))
+        return got == want
+
+    main_ok = check("main line", bool(a.strong), n, main_leg["stats"])
+    if not use_api:
+        main_leg["close"]()
+
+    # BASELINE configs[3] beside the main line: ONE 1024^3 volume as N Z-slabs, so that the driver's
+    # N = 1, 2, 4, 8 records hold the strong-scaling curve north_star names
+    strong_rec = None
+    if not a.strong and not a.no_strong_leg and a.size == 512:
+        sl = run_leg(1024, 1024, min(a.steps, 3), 1, use_api)
+        st = sl["stats"]
+        pt = float(np.median(sl["pyr"])) if sl["pyr"] and sl["pyr"][0] else None
+        strong_rec = {"workload": "1024x1024x1024 float32 lattice-blob volume%s, detect+describe, default parameters"
+                                  % ("" if ranks == 1 else " cut into %d Z-slabs" % ranks),
+                      "scaling": "strong", "n_gpus": world, "ranks": ranks, "steps": min(a.steps, 3), "warmup": 1,
+                      "ms_per_step": round(1e3 * sl["sec_per_step"], 3),
+                      "value": round(sl["voxels"] / 1e6 / sl["sec_per_step"], 2), "unit": "Mvoxel/s",
+                      "candidates": int(st["candidates"]), "keypoints": int(st["keypoints"]),
+                      "counts_ok": check("strong_1024", True, 1024, st)}
+        if pt:
+            pr = pyramid_record(1024, 1024 // ranks, pt)
+            strong_rec.update(pyramid_ms_per_gpu=round(1e3 * pt, 4), pyramid_frac_per_gpu=pr["frac"],
+                              pyramid_GBs_per_gpu=pr["achieved"])
+        if sl["per_rank"]:
+            strong_rec["per_rank_max_s"] = sl["per_rank"]
+        elif "per_rank_max_s" in st:
+            strong_rec["per_rank_max_s"] = st["per_rank_max_s"]
+        elif "stage_s" in st:
+            strong_rec["stage_s"] = st["stage_s"]
+        sl["close"]()
+        for k in ("det", "kp", "desc", "vol"):
+            sl.pop(k, None)
+        del sl
+        torch.cuda.empty_cache()
+
+    def _finish():
+        """Tear the ranks down in step: the library's RCCL communicator, the process group."""
+        if world > 1:
             dist.barrier()
             if tr is not None:
                 tr.close()
@@ -501,10 +601,14 @@ def main():
 
     if rank != 0:
         _finish()
+        if failed:
+            raise SystemExit(3)
         return
 
-    ms_per_step = 1e3 * dt / a.steps
-    value = voxels_per_step / 1e6 / (dt / a.steps)
+    dt = main_leg["sec_per_step"]
+    voxels_per_step = main_leg["voxels"]
+    ms_per_step = 1e3 * dt
+    value = voxels_per_step / 1e6 / dt
     if rt > 1:
         slabs = " cut into %d Z-slabs" % rt
     elif world == 1:
@@ -525,19 +629,17 @@ def main():
                    "parallelism": ("z-slab x%d (threads of one process, one device)" % rt) if rt > 1 else
                                   "single GPU" if world == 1 else "z-slab x%d" % world},
     }
-    out.update(stats())
-    if per_rank:
-        out["per_rank_max_s"] = per_rank
+    out.update(main_leg["stats"])
+    out["counts_ok"] = main_ok
+    if main_leg["per_rank"]:
+        out["per_rank_max_s"] = main_leg["per_rank"]
         out["transport"] = "gloo rehearsal (ranks share device 0)" if rehearse else "RCCL (ncclSend/Recv, all-reduce, all-gather)"
-    # pyramid roofline (whole Gaussian pyramid build, per GPU)
-    pbytes = pyramid_algorithmic_bytes(n, n, nz_total // world)
+    if strong_rec:
+        out["strong_1024"] = strong_rec
+    # pyramid roofline (whole Gaussian pyramid build, per GPU), ALGORITHMIC separable bytes
+    pyr = main_leg["pyr"]
     pt = float(np.median(pyr)) if pyr and pyr[0] else None
-    pyramid = None
-    if pt:
-        ach = pbytes / 1e9 / pt
-        pyramid = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_GB": round(pbytes / 1e9, 3),
-                   "seconds": round(pt, 6)}
+    pyramid = pyramid_record(n, nz_total // ranks, pt) if pt else None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -545,10 +647,11 @@ def main():
             traffic = json.load(open(tpath))
         except Exception:
             traffic = None
-    # host-resident entry (sift3d_detect_keypoints on a sift3d_make_image volume in pageable host
-    # memory): the same K steps timed the same way, H2D copy included.  Reported beside `value`,
-    # never as `value`.
-    if world == 1 and not a.sharded and not a.no_host and not rt:
+    if use_api:
+        det, kp, vol = main_leg["det"], main_leg["kp"], main_leg["vol"]
+    # host-resident entry (sift3d_detect_keypoints on a sift3d_make_image volume in host memory): the same K
+    # steps timed the same way, H2D copy included.  Reported beside `value`, never as `value`.
+    if use_api and not a.no_host:
         im = api.Image.from_array(vol.cpu().numpy())
         kp2, desc2 = api.KeypointStore(), api.DescriptorStore()
 
@@ -563,100 +666,133 @@ def main():
         torch.cuda.synchronize()
         th = (time.perf_counter() - t0) / a.steps
         assert len(kp2) == len(kp)
-        # (scalars: volume in pageable host memory, PCIe H2D inside the timed region --
-        # sift3d_detect_keypoints on a sift3d_image; never `value`)
+        # SURVEY.md 8d's metric (1) taken literally: host-resident float32 input -> host-resident stores,
+        # the PCIe H2D copy inside the timed region (sift3d_detect_keypoints on a sift3d_image); never `value`
         out["value_host_resident"] = round(voxels_per_step / 1e6 / th, 2)
         out["ms_per_step_host_resident"] = round(1e3 * th, 3)
+        out["config"]["value_host_resident_Mvoxel_s"] = out["value_host_resident"]
+        out["config"]["ms_per_step_host_resident"] = out["ms_per_step_host_resident"]
         del im
-    if world == 1 and not a.no_micro and not a.sharded and not a.strong and not rt:
+    # pyramid-only leg: the Gaussian pyramid with the device to itself (inside the step its last launches
+    # share the device with octave 0's extrema sweep, which starts as soon as octave 0 is complete)
+    pyr_alone = None
+    if use_api:
+        ts = []
+        for i in range(a.steps + 1):
+            assert det.build_pyramid_device(vol.data_ptr(), n, n, nz_total) == 0
+            if i:
+                ts.append(det.timings()["gauss_dev"])
+        pyr_alone = pyramid_record(n, nz_total, float(np.median(ts)))
+    if use_api and not a.no_micro and not a.strong:
         kb = kernel_microbench(torch, hip, n)
-        # dominant kernel = the pipeline kernel with the longest launch
-        dom = max((k for k in kb if k["in_pipeline"]), key=lambda k: k["avg_ms"])
-        tbytes = None
-        if traffic:
-            # profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950
-            # corrections applied by profiles/pmc_fir.py) is keyed by the kernel symbol
-            sym = dom["kernel"].split(" (")[0]
-            if sym in traffic:
-                tbytes = traffic[sym]["hbm_bytes"]
-        # `achieved` / `frac` price the ALGORITHMIC bytes (8 B per voxel and 1-D pass)
-        # against the HBM peak, with the launch duration measured IN THE STEP: HIP events around that
-        # launch -- the last blur of octave 0 -- on the stream it runs on, mean over the timed steps;
-        # there it shares the device with the streams that build octaves >= 1, which is also what the
-        # rocprofv3 kernel trace of a --no-micro run averages (profiles/).  `frac_alone` is the same kernel
-        # with the device to itself (the microbench leg).  `hbm_GBs` is what the kernel really moves
-        # (counter traffic / launch time): the fused y+z kernel keeps its intermediate on chip.
-        # (the MEAN over the timed steps: what rocprofv3's AverageNs of the same launches is; the launch shares
-        # the device with the other octaves' streams and its duration scatters by tens of per cent -- the
-        # median is reported beside it)
-        yz_ms = 1e3 * float(np.mean(yz_in_step)) if yz_in_step and min(yz_in_step) > 0 else None
-        launch_ms = yz_ms if yz_ms else dom["avg_ms"]
-        ach = dom["algorithmic_GB"] / (launch_ms * 1e-3)
-        out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(ach, 1),
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                           "traffic": tbytes,
-                           "avg_launch_ms": round(launch_ms, 4),
-                           "launch_timing": "in the step (mean of %d steps)" % len(yz_in_step) if yz_ms
-                                            else "kernel alone (no in-step events)",
-                           "median_launch_ms": round(1e3 * float(np.median(yz_in_step)), 4) if yz_ms else None,
-                           "frac_alone": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4),
-                           "avg_launch_ms_alone": dom["avg_ms"],
-                           "algorithmic_bytes_per_launch": int(dom["algorithmic_GB"] * 1e9),
-                           "hbm_GBs": round(tbytes / 1e9 / (launch_ms * 1e-3), 1) if tbytes else None,
-                           "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                             "passes of this kernel, committed; not measured in this run)"}
-        if pyramid:
-            # the metric BASELINE.json names: achieved HBM GB/s on the whole Gaussian pyramid build
-            out["roofline"].update(pyramid_frac=pyramid["frac"], pyramid_ms=round(1e3 * pyramid["seconds"], 4),
-                                   pyramid_GBs=pyramid["achieved"],
-                                   pyramid_algorithmic_GB=pyramid["algorithmic_GB"])
-        details = {"kernels": kb, "pyramid": pyramid}
+        alone = {k["kernel"]: k for k in kb if k["in_pipeline"]}
+        # every octave-0 pyramid launch of the timed steps, HIP events around each on the stream it runs on
+        # (sift3d_amd_timings [10..]): mean / median over the steps.  roofline.kernel = the LONGEST of them.
+        names = fir_kernel_names(api, n)
+        L = np.asarray(main_leg["launches"], np.float64)            # [steps, blurs, (x, yz)]
+        in_step = []
+        for b, (xk, yk, hw) in enumerate(names):
+            for j, (kn, nb) in enumerate(((xk, 8.0), (yk, 16.0))):
+                t = L[:, b, j]
+                if not (t > 0).all():
+                    continue
+                mean_ms, med_ms = 1e3 * float(t.mean()), 1e3 * float(np.median(t))
+                gb = nb * n ** 3 / 1e9
+                tb = traffic.get(kn.replace("true", "false"), {}).get("hbm_bytes") if traffic else None
+                al = alone.get(kn.replace("true", "false"))
+                in_step.append(dict(kernel=kn, blur=b, taps=2 * hw + 1, mean_ms=round(mean_ms, 4),
+                                    median_ms=round(med_ms, 4), min_ms=round(1e3 * float(t.min()), 4),
+                                    max_ms=round(1e3 * float(t.max()), 4), algorithmic_GB=round(gb, 4),
+                                    frac=round(gb / (mean_ms * 1e-3) / HBM_PEAK_GBS, 4),
+                                    alone_ms=al["avg_ms"] if al else None,
+                                    frac_alone=al["frac"] if al else None,
+                                    hbm_bytes=tb,
+                                    hbm_frac=round(tb / 1e9 / (mean_ms * 1e-3) / HBM_PEAK_GBS, 4) if tb else None))
+        if in_step:
+            dom = max(in_step, key=lambda k: k["mean_ms"])
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "%s (blur %d of octave 0)" % (dom["kernel"], dom["blur"]),
+                "achieved": round(dom["algorithmic_GB"] / (dom["mean_ms"] * 1e-3), 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": dom["frac"], "traffic": dom["hbm_bytes"],
+                "avg_launch_ms": dom["mean_ms"], "median_launch_ms": dom["median_ms"],
+                "launch_timing": "the LONGEST octave-0 pyramid launch in the step: HIP events around every x and "
+                                 "fused y+z launch on its stream, mean over the %d timed steps (what rocprofv3's "
+                                 "average of the same launches is)" % len(L),
+                "frac_alone": dom["frac_alone"], "avg_launch_ms_alone": dom["alone_ms"],
+                "algorithmic_bytes_per_launch": int(dom["algorithmic_GB"] * 1e9),
+                "hbm_GBs": round(dom["hbm_bytes"] / 1e9 / (dom["mean_ms"] * 1e-3), 1) if dom["hbm_bytes"] else None,
+                "hbm_frac": dom["hbm_frac"],
+                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                  "kernel, committed; not measured in this run)"}
+        else:
+            out["roofline"] = dict(pyramid or {}, kernel="Gaussian pyramid (all k_fir_* launches)", traffic=None)
+        details = {"kernels": kb, "in_step_launches": in_step, "pyramid": pyramid, "pyramid_alone": pyr_alone}
         dpath = os.path.join(ROOT, "profiles", "describe_model.json")
         if os.path.exists(dpath):
             try:
                 dm = json.load(open(dpath))
                 dsec = out.get("stage_s", {}).get("describe")
-                if dsec and dm.get("valu_insts"):
-                    # k_describe is bound by instruction issue (VALU and the LDS pipe), not by HBM: what the
-                    # hardware counters of the committed profile say for this kernel (instruction and
-                    # LDS-array-cycle counts are properties of the code and the workload; the seconds are
-                    # this run's)
-                    cu_cycles = dsec * 2.4e9 * 256
-                    simd_rate = 256 * 4 * 2.4e9 / dm.get("cycles_per_valu", 2.5)
-                    dm["seconds"] = dsec
-                    dm["valu_frac"] = round(dm["valu_insts"] / dsec / simd_rate, 4)
-                    dm["lds_array_frac"] = round(dm.get("lds_array_cycles", 0) / cu_cycles, 4)
-                    if dm.get("wave_quad_cycles"):
+                clk = [c for c in main_leg["dclk"] if c]
+                if dsec and dm.get("valu_insts") and clk:
+                    # k_describe is bound by instruction issue (VALU and the LDS pipe), not by HBM.  Clock-free:
+                    # the kernel's own shader-cycle count (its first, persistent wave: s_memtime at entry and
+                    # exit, measured in THIS run) against the committed counter totals per launch (instruction
+                    # and LDS-array-cycle counts are properties of the code and the workload).  One wave64 VALU
+                    # instruction occupies a SIMD for 2 cycles (MI355X_MICROARCH.md: SIMD-32).
+                    cyc = float(np.median([c[0] for c in clk]))
+                    sec = float(np.median([c[1] for c in clk]))
+                    cus, simds = 256, 1024
+                    dm = {k: v for k, v in dm.items() if k not in ("lds_issue_model", "issue_model_note")}
+                    dm.update(seconds=dsec, kernel_cycles=cyc, kernel_seconds_100MHz_counter=round(sec, 6),
+                              clock_GHz=round(cyc / sec / 1e9, 3),
+                              valu_busy=round(dm["valu_insts"] * 2.0 / (simds * cyc), 4),
+                              lds_array_busy=round(dm.get("lds_array_cycles", 0) / (cus * cyc), 4))
+                    if dm.get("wave_quad_cycles") and dm.get("waves"):
                         w = dm["wave_quad_cycles"]
+                        dm["profiled_kernel_cycles"] = round(4.0 * w / dm["waves"])
                         dm["wave_time_split"] = {"waiting_at_s_waitcnt": round(dm.get("wait_any", 0) / w, 3),
                                                  "issue_stalled": round(dm.get("wait_inst_any", 0) / w, 3),
                                                  "issue_stalled_on_lds": round(dm.get("wait_inst_lds", 0) / w, 3)}
-                    dm["frac"] = max(dm["valu_frac"], dm["lds_array_frac"])
+                    dm["frac"] = max(dm["valu_busy"], dm["lds_array_busy"])
                     details["describe"] = dm
-                    out["roofline"].update(describe_ms=round(1e3 * dsec, 3), describe_valu_frac=dm["valu_frac"],
-                                           describe_lds_array_frac=dm["lds_array_frac"])
-            except Exception:
-                pass
+                    out["roofline"].update(describe_ms=round(1e3 * dsec, 3), describe_clock_GHz=dm["clock_GHz"],
+                                           describe_valu_busy=dm["valu_busy"],
+                                           describe_lds_array_busy=dm["lds_array_busy"])
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("bench.py: describe model skipped (%r)\n" % (e,))
         out["details"] = details
     else:
-        out["roofline"] = dict(pyramid or {}, kernel="Gaussian pyramid (all k_fir_* launches)",
-                               traffic=None)
-        if pyramid:
-            out["roofline"].update(pyramid_frac=pyramid["frac"], pyramid_ms=round(1e3 * pyramid["seconds"], 4),
-                                   pyramid_GBs=pyramid["achieved"])
-        if yz_in_step and min(yz_in_step) > 0:
-            # (no microbench leg: the in-step launch of the dominant kernel, as the default run reports it)
-            yz_ms = 1e3 * float(np.mean(yz_in_step))
-            out["roofline"].update(dominant_kernel="k_fir_yz_dma<8, 32> (last blur of octave 0)",
-                                   dominant_avg_launch_ms=round(yz_ms, 4),
-                                   dominant_frac=round(16.0 * n ** 3 / 1e9 / (yz_ms * 1e-3) / HBM_PEAK_GBS, 4))
+        out["roofline"] = dict(pyramid or {}, kernel="Gaussian pyramid (all k_fir_* launches)", traffic=None)
+    if pyramid:
+        # the metric BASELINE.json names: achieved HBM GB/s on the whole Gaussian pyramid build.
+        #   pyramid_frac      ALGORITHMIC separable bytes (24 B per voxel and blur) / in-step time
+        #   pyramid_hbm_frac  bytes that really reach HBM (rocprofv3 FETCH_SIZE / WRITE_SIZE of one whole pyramid
+        #                     build, profiles/traffic.json "pyramid_build") / the same time: the fused y+z pass
+        #                     keeps its intermediate on chip, so this is the smaller number
+        out["roofline"].update(pyramid_frac=pyramid["frac"], pyramid_ms=round(1e3 * pyramid["seconds"], 4),
+                               pyramid_GBs=pyramid["achieved"], pyramid_algorithmic_GB=pyramid["algorithmic_GB"])
+        pb = (traffic or {}).get("pyramid_build_%d" % n) if ranks == 1 and nz_total == n else None
+        if pb:
+            out["roofline"].update(pyramid_hbm_GB=round(pb["hbm_bytes"] / 1e9, 3),
+                                   pyramid_hbm_frac=round(pb["hbm_bytes"] / 1e9 / pyramid["seconds"] / HBM_PEAK_GBS, 4))
+        if pyr_alone:
+            out["roofline"].update(pyramid_alone_ms=round(1e3 * pyr_alone["seconds"], 4),
+                                   pyramid_alone_frac=pyr_alone["frac"])
+            if pb:
+                out["roofline"]["pyramid_alone_hbm_frac"] = round(
+                    pb["hbm_bytes"] / 1e9 / pyr_alone["seconds"] / HBM_PEAK_GBS, 4)
     if not a.no_cpu and world == 1:          # the CPU leg runs at N = 1 only
         out["cpu_baseline"] = cpu_baseline()
     if "details" in out:                     # the long per-kernel lists go last
         out["details"] = out.pop("details")
+    if failed:
+        out["counts_error"] = failed
     print(json.dumps(out))
     sys.stdout.flush()
     _finish()
+    if failed:
+        sys.stderr.write("bench.py: WRONG RESULT: %s\n" % "; ".join(failed))
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -89,10 +89,28 @@ sift3d_amd_image_info(const sift3d_image *im, int *dims4, double *units3);
  * [5] describe  [6] pyramid kernels only, device time from HIP events
  * [7] whole detect, device time  [8] whole describe, device time
  * [9] the LAST fused y+z FIR launch of octave 0 alone (HIP events on its stream; 0 when that blur did
- *     not take the fused kernel) -- in the pipeline it shares the device with the octave streams.  */
-#define SIFT3D_AMD_NUM_TIMINGS 10
+ *     not take the fused kernel) -- in the pipeline it shares the device with the octave streams.
+ * [10 .. 10+B-1]    the x-pass launch of blur s = 0 .. B-1 of octave 0 (B = SIFT3D_AMD_TIMED_BLURS),
+ * [10+B .. 10+2B-1] its fused y+z launch: HIP events around each launch on the stream it runs on (0 for a
+ *     blur that did not take the fused kernel).  Every octave-0 pyramid launch of the step is timed, so the
+ *     LONGEST in-step launch can be named (bench.py's roofline.kernel).
+ * Since round 5 the stages overlap: [1] ends with the last of the pyramid's three chains, [2] and [3] start on
+ * the main stream when octave 0 is complete -- their sum can exceed [7]. */
+#define SIFT3D_AMD_TIMED_BLURS 8
+#define SIFT3D_AMD_NUM_TIMINGS (10 + 2 * SIFT3D_AMD_TIMED_BLURS)
 SIFT3D_AMD_API const double *
 sift3d_amd_timings(const sift3d_detector *det);
+
+/* max|v| + the Gaussian pyramid alone of a float32 volume in device memory (the first part of
+ * sift3d_amd_detect_keypoints_device: sift.c:645-649, 662-711), blocking; timings()[1] is its device time. */
+SIFT3D_AMD_API int
+sift3d_amd_build_pyramid_device(sift3d_detector *det, const float *d_volume, int nx, int ny, int nz,
+                                double ux, double uy, double uz);
+
+/* Shader cycles and seconds (from the device's constant 100 MHz counter) of the fast descriptor kernel of the
+ * last sift3d_extract_descriptors on `det`, measured by the kernel itself (sift3d_hip_describe_clock). */
+SIFT3D_AMD_API int
+sift3d_amd_describe_clock(const sift3d_detector *det, double *cycles, double *seconds);
 
 /* Number of DoG extrema before orientation filtering in the last detect. */
 SIFT3D_AMD_API int
@@ -470,6 +488,19 @@ sift3d_hip_extrema_gauss6_phase(const float *const *d_g, const float *d_absmax, 
  * Both return 1 when the configuration is not covered. */
 SIFT3D_AMD_API int sift3d_hip_dogmax_sub(const float *const *d_g, int nx, int ny, int nz, float *d_est,
                                          void *stream);
+/* Phase 2 (scan + emission) of the two entries above/below for ALL octaves of a call in two launches instead
+ * of two per octave: octs[i] = what phase 1 of octave i was given.  Appends to d_out at *d_count in (octave,
+ * level, z, y, x) order (sift.c:835-868).  Returns 1 when n_oct exceeds what one launch takes. */
+typedef struct {
+    const float *const *d_g;   /* the octave's six Gaussian levels */
+    int nx, ny, nz;
+    int tag0;
+    void *d_work;
+    size_t work_bytes;
+} sift3d_hip_extrema_oct;
+SIFT3D_AMD_API int
+sift3d_hip_extrema_gauss6_finish(const sift3d_hip_extrema_oct *octs, int n_oct, double peak_thresh,
+                                 sift3d_hip_cand *d_out, uint32_t cap, uint32_t *d_count, void *stream);
 SIFT3D_AMD_API int
 sift3d_hip_extrema_gauss6_est_phase(const float *const *d_g, const float *d_est, float *d_exact, int nx,
                                     int ny, int nz, int tag0, double peak_thresh, sift3d_hip_cand *d_out,
@@ -536,6 +567,12 @@ SIFT3D_AMD_API size_t sift3d_hip_describe_wlut_floats(int nlevels);
 SIFT3D_AMD_API int
 sift3d_hip_describe_wlut(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
                          uint32_t n, float *d_hist, float *d_wlut, void *stream);
+/* Clock probe of the last descriptor launch through d_wlut (the fast kernel; exact != 0: the reference-order
+ * one): shader cycles and ticks of the constant 100 MHz counter during which the launch's first -- persistent --
+ * wave was alive.  cycles / (ticks / 1e8) = the clock the device held under the kernel.  Blocks on `stream`. */
+SIFT3D_AMD_API int
+sift3d_hip_describe_clock(const float *d_wlut, int nlevels, int exact, uint64_t *cycles, uint64_t *ticks,
+                          void *stream);
 /* The same with a second destination: d_hist2 (device memory, may be NULL) receives a copy of every
  * histogram -- the matcher's input stays in HBM (sift3d_amd_descriptor_store_keep_device). */
 SIFT3D_AMD_API int

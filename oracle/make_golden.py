@@ -343,6 +343,14 @@ def main():
             "g3_switch_aniso", so.synth_lattice((80, 112, 112), seed=19), units=(1.0, 0.8, 0.8),
             store_levels=False, params=dict(peak_thresh=0.05, corner_thresh=0.3),
             input_spec=dict(gen="lattice", n=[80, 112, 112], seed=19))
+    # Round 5: sigma0 = 8 -- the octave filters are 31 ... 75 taps wide (half width ceil(3 sigma),
+    # imutil.c:1275-1277), beyond the 65-tap tables of the device's fast kernels: the reference accepts any
+    # sigma0 >= 0 (sift.c:553-565) and so must the drop-in
+    if a.only and "g3_sigma8" in a.only.split(","):
+        jobs["g3_sigma8"] = lambda: end_to_end(
+            "g3_sigma8", so.synth_survey(96), store_levels=False,
+            params=dict(sigma0=8.0, peak_thresh=0.01, corner_thresh=0.1),
+            input_spec=dict(gen="survey", n=96))
     if a.only and "g5_slab8" in a.only.split(","):
         # BASELINE configs[3]'s slab geometry at 1/16 of its voxels: 256 x 256 x 1024 (eight 128-plane
         # Z-slabs, o_shard = 2) -- the sharded GPU tests compare with THIS, not with the single-GPU API

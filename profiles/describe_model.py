@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Issue-rate model of k_describe (profiles/describe_model.json, read by bench.py).
+"""Counter totals of k_describe (profiles/describe_model.json, read by bench.py).
 
     # on the GPU box (cd /tmp && export TMPDIR=/tmp first), three runs of this script:
     rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d gpurun_out/pmc_desc/a -o run --output-format csv -- python3 profiles/describe_model.py --run
@@ -67,36 +67,24 @@ def parse(d, voxels):
                lds_bank_conflict_cycles=c.get("SQ_LDS_BANK_CONFLICT"), waves=c.get("SQ_WAVES"),
                wave_quad_cycles=c.get("SQ_WAVE_CYCLES"), wait_any=c.get("SQ_WAIT_ANY"),
                wait_inst_any=c.get("SQ_WAIT_INST_ANY"), wait_inst_lds=c.get("SQ_WAIT_INST_LDS"),
-               cycles_per_valu=2.5,
-               note="wave-instructions per launch (rocprofv3 --pmc); one VALU instruction occupies a "
-                    "SIMD for ~2.5 cycles (scratch microbenchmark, plain f32 ops); "
-                    "lds_array_cycles is summed over the 256 CUs")
+               note="wave-instructions per launch (rocprofv3 --pmc); lds_array_cycles is summed over the 256 CUs; "
+                    "bench.py prices both against the kernel's own cycle count of its run (clock probe)")
     if voxels and c.get("SQ_INSTS_VALU"):
         out["valu_insts_per_64_voxels"] = round(64.0 * c["SQ_INSTS_VALU"] / voxels, 1)
         out["lds_insts_per_64_voxels"] = round(64.0 * c.get("SQ_INSTS_LDS", 0) / voxels, 1)
         out["lds_array_cycles_per_64_voxels"] = round(64.0 * c.get("SQ_LDS_IDX_ACTIVE", 0) / voxels, 1)
-    # LDS instruction-issue model.  profiles/microbench/lds_cost.hip: on gfx950 one LDS instruction
-    # occupies the CU's LDS pipe for a time set by its kind and dwords per lane, NOT by the number
-    # of active lanes (cycles at 2.4 GHz, 16 waves per CU issuing back to back):
-    cost = dict(read_b32=3.1, read_b128=4.6, write_b32=4.35, write2_b32=6.4)
-    # k_describe per batch of 64 window voxels (static count of the main loop, sift3d_describe.hip):
-    mix = dict(rmw_read_b32=32, rmw_write_b32=32,           # 2 passes x 16 rounds, 2 voxels per round
-               record_read_b128=24,                         # 3 fields x 4 chunks x 2 passes
-               record_write2_b32=6, record_write_b32=2,     # 7 dwords per lane per pass
-               face_read_b128=4, octant_read_b32=1, queue_read_b32=1, queue_write_b32=2)
-    out["issue_model_note"] = ("an LDS instruction priced at what the back-to-back microbenchmark measured "
-                               "(lds_cost_mi355x.txt); the counters (SQ_LDS_IDX_ACTIVE, SQ_WAIT_INST_LDS) are "
-                               "what the hardware reports for this kernel -- bench.py prints both")
-    cyc = (mix["rmw_read_b32"] * cost["read_b32"] + mix["rmw_write_b32"] * cost["write_b32"] +
-           mix["record_read_b128"] * cost["read_b128"] + mix["record_write2_b32"] * cost["write2_b32"] +
-           mix["record_write_b32"] * cost["write_b32"] + mix["face_read_b128"] * cost["read_b128"] +
-           (mix["octant_read_b32"] + mix["queue_read_b32"]) * cost["read_b32"] +
-           mix["queue_write_b32"] * cost["write_b32"])
-    out["lds_issue_model"] = dict(cost_cycles_per_instruction=cost, instructions_per_64_voxels=mix,
-                                  lds_pipe_cycles_per_64_voxels=round(cyc, 1), clock_hz=2.4e9, cus=256,
-                                  seconds_if_lds_bound=round(voxels / 64.0 / 256.0 * cyc / 2.4e9, 5) if voxels else None,
-                                  note="the LDS pipe of a CU is the binding resource of k_describe: "
-                                       "frac = seconds_if_lds_bound / measured seconds")
+    # Clock-free fractions (round 5; the 2.4 GHz constant and the LDS issue model of rounds 2-4 are gone: the
+    # chip does not hold 2.4 GHz under this kernel, and the model priced more pipe cycles than the waves were
+    # alive).  Every wave of the launch is persistent, so SQ_WAVE_CYCLES (units of 4 cycles, summed over the
+    # waves) * 4 / waves = the kernel's duration in shader cycles; the LDS array's busy cycles are summed over
+    # the 256 CUs, and one wave64 VALU instruction occupies one of the 1024 SIMDs for 2 cycles (guide: SIMD-32).
+    if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAVES"):
+        kc = 4.0 * c["SQ_WAVE_CYCLES"] / c["SQ_WAVES"]
+        out["profiled_kernel_cycles"] = round(kc)
+        out["lds_array_busy"] = round(c.get("SQ_LDS_IDX_ACTIVE", 0) / (256.0 * kc), 4)
+        out["valu_busy"] = round(2.0 * c.get("SQ_INSTS_VALU", 0) / (1024.0 * kc), 4)
+        if c.get("GRBM_GUI_ACTIVE"):
+            out["grbm_gui_active_cycles"] = c["GRBM_GUI_ACTIVE"]
     print(json.dumps(out, indent=1))
 
 

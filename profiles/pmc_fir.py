@@ -4,6 +4,13 @@
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 profiles/pmc_fir.py
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 profiles/pmc_fir.py
     python3 profiles/pmc_fir.py --parse gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/traffic.json
+
+Round 5: the HBM bytes of ONE WHOLE pyramid build (every kernel of every octave), for bench.py's
+`pyramid_hbm_frac` -- two more passes over `--pyramid` (two builds and nothing else), parsed with two more
+directories:
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_pyr_fetch -- python3 profiles/pmc_fir.py --pyramid
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_pyr_write -- python3 profiles/pmc_fir.py --pyramid
+    python3 profiles/pmc_fir.py --parse <fetch> <write> <pyr fetch> <pyr write> > profiles/traffic.json
 """
 import csv
 import glob
@@ -48,6 +55,52 @@ def run(n=512, reps=3):
     torch.cuda.synchronize()
 
 
+def run_pyramid(n=512, builds=2):
+    """`builds` whole Gaussian pyramid builds (sift3d_amd_build_pyramid_device) and nothing else: every
+    dispatch of the process belongs to one, so the per-build HBM bytes are the counter sums / builds."""
+    import torch
+    from sift3d_amd import api, hip
+    _require_built()
+    vol = torch.empty((n, n, n), device="cuda")
+    hip.synth_lattice(vol, 0, 11)
+    torch.cuda.synchronize()
+    det = api.Detector()
+    for _ in range(builds):
+        assert det.build_pyramid_device(vol.data_ptr(), n, n, n) == 0
+    torch.cuda.synchronize()
+
+
+def parse_pyramid(fetch_dir, write_dir, n=512, builds=2):
+    """HBM bytes of one whole pyramid build: sums over every dispatch of run_pyramid() but the volume's
+    synthesis, / builds; FETCH_SIZE doubled as in parse()."""
+    def total(d, name):
+        tot, by = 0.0, {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != name or "synth" in r["Kernel_Name"]:
+                    continue
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                v = float(r["Counter_Value"])
+                tot += v
+                by[k] = by.get(k, 0.0) + v
+        return tot, by
+    fe, fby = total(fetch_dir, "FETCH_SIZE")
+    wr, wby = total(write_dir, "WRITE_SIZE")
+    num_oct = 0
+    m = n
+    alg = 0
+    while m >= 8:
+        alg += 24 * m ** 3 * (6 if num_oct == 0 else 5)
+        num_oct += 1
+        m //= 2
+    hbm = (2.0 * fe + wr) * 1024.0 / builds
+    by = {k: round((2.0 * fby.get(k, 0.0) + wby.get(k, 0.0)) * 1024.0 / builds) for k in set(fby) | set(wby)}
+    return dict(hbm_bytes=round(hbm), algorithmic_bytes=alg, ratio=round(hbm / alg, 3), builds=builds,
+                note="every kernel of sift3d_amd_build_pyramid_device (max|v|, all FIR passes of all octaves, "
+                     "down-sampling): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 summed over its dispatches",
+                hbm_bytes_by_kernel=dict(sorted(by.items(), key=lambda kv: -kv[1])))
+
+
 def parse(fetch_dir, write_dir, n=512):
     """Per kernel: mean counter value per dispatch.  FETCH_SIZE / WRITE_SIZE are in KiB-ish units of
     1024 B (guide: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024); on gfx950 FETCH_SIZE reports half
@@ -79,6 +132,12 @@ def parse(fetch_dir, write_dir, n=512):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--parse":
-        print(json.dumps(parse(sys.argv[2], sys.argv[3]), indent=1, sort_keys=True))
+        # --parse <fetch dir> <write dir> [<pyramid fetch dir> <pyramid write dir>]
+        res = parse(sys.argv[2], sys.argv[3])
+        if len(sys.argv) > 5:
+            res["pyramid_build_512"] = parse_pyramid(sys.argv[4], sys.argv[5])
+        print(json.dumps(res, indent=1, sort_keys=True))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--pyramid":
+        run_pyramid()
     else:
         run_guarded()

@@ -19,7 +19,8 @@ from . import _native
 SIFT3D_SUCCESS = 0
 SIFT3D_FAILURE = -1
 SIFT3D_DOUBLE, SIFT3D_FLOAT, SIFT3D_INT = 0, 1, 2
-NUM_TIMINGS = 10
+TIMED_BLURS = 8
+NUM_TIMINGS = 10 + 2 * TIMED_BLURS
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -71,6 +72,9 @@ def lib():
         "sift3d_amd_image_set_units": (C.c_int, [vp, C.c_double, C.c_double, C.c_double]),
         "sift3d_amd_timings": (C.POINTER(C.c_double), [vp]),
         "sift3d_amd_num_candidates": (C.c_int, [vp]),
+        "sift3d_amd_describe_clock": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "sift3d_amd_build_pyramid_device": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                                      C.c_double]),
         "sift3d_amd_image_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
         "sift3d_amd_detector_set_cuboid_extrema": (C.c_int, [vp, C.c_int]),
         "sift3d_amd_detector_set_dogmax_pass": (C.c_int, [vp, C.c_int]),
@@ -387,7 +391,25 @@ class Detector:
         p = lib().sift3d_amd_timings(self.h)
         names = ("scale", "gauss", "dog", "extrema", "orient", "describe", "gauss_dev",
                  "detect_wall", "describe_wall", "yz_last")
-        return dict(zip(names, [p[i] for i in range(NUM_TIMINGS)]))
+        return dict(zip(names, [p[i] for i in range(len(names))]))
+
+    def describe_clock(self):
+        """(shader cycles, seconds) of the fast descriptor kernel of the last extract_descriptors, measured by
+        the kernel itself (its first, persistent wave); None when nothing was recorded."""
+        c, t = C.c_double(), C.c_double()
+        if lib().sift3d_amd_describe_clock(self.h, C.byref(c), C.byref(t)) != 0 or t.value <= 0:
+            return None
+        return c.value, t.value
+
+    def launch_timings(self):
+        """Octave 0's pyramid launches of the last detect, HIP events around each on its stream:
+        (x-pass seconds, fused y+z seconds) per blur s = 0 .. ngl-1; 0.0 where a blur did not take the
+        fused kernel."""
+        p = lib().sift3d_amd_timings(self.h)
+        return [(p[10 + b], p[10 + TIMED_BLURS + b]) for b in range(TIMED_BLURS)]
+
+    def build_pyramid_device(self, ptr, nx, ny, nz, units=(1.0, 1.0, 1.0)):
+        return lib().sift3d_amd_build_pyramid_device(self.h, ptr, nx, ny, nz, *map(float, units))
 
     def num_candidates(self):
         return lib().sift3d_amd_num_candidates(self.h)

@@ -213,6 +213,16 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         sexp[threadIdx.x] = s3d_exp2_tab[threadIdx.x];
     }
     __syncthreads();              // the only workgroup barrier: from here on the waves are independent
+    // clock probe (round 5): the first wave of the launch lives as long as the kernel (the waves are
+    // persistent: they loop over the work counter); it notes the shader-clock and the constant 100 MHz
+    // counters when it starts and when it leaves, and stores the two differences behind the work counters --
+    // the clock the chip HELD under this kernel, which bench.py prices the counter fractions with
+    const bool probe = work && blockIdx.x == 0 && threadIdx.x == 0;
+    long long probe_c0 = 0, probe_w0 = 0;
+    if (probe) {
+        probe_c0 = clock64();
+        probe_w0 = wall_clock64();
+    }
     // Keypoints are handed out one at a time from a counter (`work`; list order = widest windows first): a
     // wave that has finished its keypoint takes the next one.  With a fixed assignment of four keypoints to a
     // workgroup the three faster waves idled until the slowest was done -- their slots and LDS are released
@@ -822,6 +832,11 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     }
     wave_sync();                  // (the histogram is cleared for the next keypoint behind these reads)
     }
+    if (probe) {
+        unsigned long long *slot = reinterpret_cast<unsigned long long *>(work - (EXACT ? 0 : 1) + (EXACT ? 4 : 8));
+        slot[0] = (unsigned long long)(clock64() - probe_c0);
+        slot[1] = (unsigned long long)(wall_clock64() - probe_w0);
+    }
 }
 
 extern "C" {
@@ -1039,6 +1054,22 @@ int sift3d_hip_describe_ex(const sift3d_hip_level *d_levels, int nlevels, const 
     hipLaunchKernelGGL(k_desc_wlut, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, d_levels, nlevels,
                        d_wlut);
     return describe_launch(d_levels, nlevels, d_kp, n, n_exact, d_hist, d_hist2, d_wlut, stream);
+}
+
+// shader cycles and 100 MHz ticks the first wave of the last descriptor launch (fast kernel; exact != 0: the
+// reference-order kernel) was alive -- persistent waves: the kernel's duration.  Blocks on `stream`.
+int sift3d_hip_describe_clock(const float *d_wlut, int nlevels, int exact, uint64_t *cycles, uint64_t *ticks,
+                              void *stream)
+{
+    if (!d_wlut || nlevels < 1 || !cycles || !ticks)
+        return SIFT3D_FAILURE;
+    uint64_t v[2] = { 0, 0 };
+    const uint32_t *ctr = reinterpret_cast<const uint32_t *>(d_wlut + (size_t)nlevels * WL_STRIDE);
+    HIPCHK(hipMemcpyAsync(v, ctr + (exact ? 4 : 8), sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    *cycles = v[0];
+    *ticks = v[1];
+    return SIFT3D_SUCCESS;
 }
 
 int sift3d_hip_describe_wlut2(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,

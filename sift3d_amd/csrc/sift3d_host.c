@@ -120,8 +120,11 @@ struct _sift3d_detector {
     void *oct_stream;      /* octaves >= 1 of the pyramid, beside the last levels of octave 0 */
     void *side_stream;     /* ... and their levels that no later octave depends on */
     void *ev_fork, *ev_join, *ev_join2;
-    void *ev_yz[2];        /* around the last fused y+z launch of octave 0 */
-    int yz_timed;
+    void *ev_blur[SIFT3D_AMD_TIMED_BLURS][3]; /* octave 0, blur s: before its x pass, between x and the fused
+                            * y+z launch, after it (on the stream they run on) */
+    unsigned yz_timed;     /* bit s: blur s of octave 0 took the fused y+z kernel in the last detect */
+    void *ev_pyr[2];       /* the pyramid's last launch on the octave stream / the side stream */
+    int pyr_chains;        /* the last detect built its pyramid on three chains (ev_pyr are recorded) */
     void *ev_oct[32];      /* per octave: its downsampling source level is complete */
     int device;            /* HIP device of the streams / pyramids */
     void *ev[8];
@@ -904,11 +907,8 @@ static int build_filters(sift3d_detector *d)
         }
         if (gauss_filter(&d->filt[i], sqrt(s_next * s_next - s_cur * s_cur)))
             return SIFT3D_FAILURE;
-        if (d->filt[i].width > SIFT3D_HIP_MAX_TAPS) {
-            ERR("sift3d_amd: a %d-tap Gaussian exceeds the device kernels' limit of %d taps \n",
-                d->filt[i].width, SIFT3D_HIP_MAX_TAPS);
-            return SIFT3D_FAILURE;
-        }
+        /* (any width: filters of more than SIFT3D_HIP_MAX_TAPS taps take the chunked literal kernel,
+         * sift3d_hip_fir -- the reference accepts every sigma0 >= 0, sift.c:553-565) */
     }
     return SIFT3D_SUCCESS;
 }
@@ -1220,8 +1220,10 @@ void sift3d_free_detector(sift3d_detector *d)
     sift3d_hip_event_destroy(d->ev_fork);
     sift3d_hip_event_destroy(d->ev_join);
     sift3d_hip_event_destroy(d->ev_join2);
-    sift3d_hip_event_destroy(d->ev_yz[0]);
-    sift3d_hip_event_destroy(d->ev_yz[1]);
+    for (i = 0; i < SIFT3D_AMD_TIMED_BLURS * 3; i++)
+        sift3d_hip_event_destroy(d->ev_blur[i / 3][i % 3]);
+    sift3d_hip_event_destroy(d->ev_pyr[0]);
+    sift3d_hip_event_destroy(d->ev_pyr[1]);
     for (i = 0; i < 32; i++)
         sift3d_hip_event_destroy(d->ev_oct[i]);
     sift3d_hip_stream_destroy(d->side_stream);
@@ -1246,12 +1248,29 @@ const double *sift3d_amd_timings(const sift3d_detector *dc)
     sift3d_detector *d = (sift3d_detector *)dc;
     if (d->t_pending & 1) {
         d->t[0] = stage_seconds(d->ev[0], d->ev[1]);
+        int b, last = -1;
+        /* the pyramid ends with the LAST of its chains (octave 0 on the main stream; the first levels of
+         * the smaller octaves; their last levels); the stages after it start on the main stream when
+         * octave 0 is complete, so [2] and [3] overlap the tail of [1] */
         d->t[1] = stage_seconds(d->ev[1], d->ev[2]);
+        if (d->pyr_chains)
+            for (b = 0; b < 2; b++) {
+                const double tc = stage_seconds(d->ev[1], d->ev_pyr[b]);
+                if (tc > d->t[1] || isnan(tc))
+                    d->t[1] = tc;
+            }
         d->t[2] = stage_seconds(d->ev[2], d->ev[3]);
         d->t[3] = stage_seconds(d->ev[3], d->ev[4]);
         d->t[4] = stage_seconds(d->ev[4], d->ev[5]);
         d->t[6] = d->t[1];
-        d->t[9] = d->yz_timed ? stage_seconds(d->ev_yz[0], d->ev_yz[1]) : 0.0;
+        for (b = 0; b < SIFT3D_AMD_TIMED_BLURS; b++) {
+            const int on = (d->yz_timed >> b) & 1;
+            d->t[10 + b] = on ? stage_seconds(d->ev_blur[b][0], d->ev_blur[b][1]) : 0.0;
+            d->t[10 + SIFT3D_AMD_TIMED_BLURS + b] = on ? stage_seconds(d->ev_blur[b][1], d->ev_blur[b][2]) : 0.0;
+            if (on)
+                last = b;
+        }
+        d->t[9] = last >= 0 ? d->t[10 + SIFT3D_AMD_TIMED_BLURS + last] : 0.0;
     }
     if (d->t_pending & 2)
         d->t[5] = stage_seconds(d->ev[6], d->ev[7]);
@@ -1259,6 +1278,17 @@ const double *sift3d_amd_timings(const sift3d_detector *dc)
     return d->t;
 }
 int sift3d_amd_num_candidates(const sift3d_detector *d) { return d->ncand; }
+
+int sift3d_amd_describe_clock(const sift3d_detector *d, double *cycles, double *seconds)
+{
+    uint64_t c = 0, t = 0;
+    if (!d || !d->d_wlut || !d->num_octaves || !cycles || !seconds ||
+        sift3d_hip_describe_clock(d->d_wlut, d->num_octaves * d->ngl, 0, &c, &t, d->stream))
+        return SIFT3D_FAILURE;
+    *cycles = (double)c;
+    *seconds = (double)t * 1e-8;
+    return SIFT3D_SUCCESS;
+}
 
 /* max|DoG| of every level of the last detect call (the dogmax scan, sift.c:821-826): out[o * ndl + s],
  * capacity `cap` floats; returns the number of values or -1 */
@@ -1341,13 +1371,16 @@ static int ensure_device(sift3d_detector *d)
         !(d->oct_stream = sift3d_hip_stream_create_high()) ||
         !(d->side_stream = sift3d_hip_stream_create_high()) || !(d->ev_fork = sift3d_hip_event_create()) ||
         !(d->ev_join = sift3d_hip_event_create()) || !(d->ev_join2 = sift3d_hip_event_create()) ||
-        !(d->ev_yz[0] = sift3d_hip_event_create()) || !(d->ev_yz[1] = sift3d_hip_event_create()))
+        !(d->ev_pyr[0] = sift3d_hip_event_create()) || !(d->ev_pyr[1] = sift3d_hip_event_create()))
         return SIFT3D_FAILURE;
     for (i = 0; i < 32; i++)
         if (!(d->ev_oct[i] = sift3d_hip_event_create()))
             return SIFT3D_FAILURE;
     for (i = 0; i < 8; i++)
         if (!(d->ev[i] = sift3d_hip_event_create()) || !(d->ev_chunk[i] = sift3d_hip_event_create()))
+            return SIFT3D_FAILURE;
+    for (i = 0; i < SIFT3D_AMD_TIMED_BLURS * 3; i++)
+        if (!(d->ev_blur[i / 3][i % 3] = sift3d_hip_event_create()))
             return SIFT3D_FAILURE;
     return upload_mesh();
 }
@@ -1402,7 +1435,7 @@ static int ensure_dog_octave(sift3d_detector *d, int o)
  * caller then scales the image first) */
 static int blur_level(sift3d_detector *d, const float *src, float *dst, const int *dims,
                       const double *lu, const filter_t *f, void *stream, float *tmp_a, float *tmp_b,
-                      int time_yz, const float *d_scale_max)
+                      int slot, const float *d_scale_max)
 {
     const float *in = src;
     float *outs[3];
@@ -1421,6 +1454,10 @@ static int blur_level(sift3d_detector *d, const float *src, float *dst, const in
         a.axis = 0; a.width = f->width; a.taps = f->taps;
         a.unit_factor = (float)(1.0 / lu[0]);
         a.n_glob = dims[2]; a.z_lo = 0; a.z_hi = dims[2];
+        if (slot >= SIFT3D_AMD_TIMED_BLURS)
+            slot = -1;
+        if (slot >= 0)
+            sift3d_hip_event_record(d->ev_blur[slot][0], stream);
         if (d_scale_max) {
             rc = sift3d_hip_fir_x_scaled(&a, d_scale_max, stream);
             if (rc == 1)
@@ -1429,14 +1466,14 @@ static int blur_level(sift3d_detector *d, const float *src, float *dst, const in
                 return SIFT3D_FAILURE;
         } else if (sift3d_hip_fir(&a, stream))
             return SIFT3D_FAILURE;
-        if (time_yz)
-            sift3d_hip_event_record(d->ev_yz[0], stream);
+        if (slot >= 0)
+            sift3d_hip_event_record(d->ev_blur[slot][1], stream);
         rc = sift3d_hip_fir_yz_u1(tmp_a, dst, dims[0], dims[1], dims[2], f->taps, f->width,
                                   dims[2], 0, 0, dims[2], stream);
         if (rc == SIFT3D_SUCCESS) {
-            if (time_yz) {
-                sift3d_hip_event_record(d->ev_yz[1], stream);
-                d->yz_timed = 1;
+            if (slot >= 0) {
+                sift3d_hip_event_record(d->ev_blur[slot][2], stream);
+                d->yz_timed |= 1u << slot;
             }
             return SIFT3D_SUCCESS;
         }
@@ -1505,7 +1542,7 @@ static int host_threads(size_t n)
 }
 
 static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int ny, int nz,
-                            double ux, double uy, double uz, sift3d_keypoint_store *kp)
+                            double ux, double uy, double uz, sift3d_keypoint_store *kp, int pyramid_only)
 {
     const size_t n0 = (size_t)nx * ny * nz;
     const int dims_changed = !d->have_im || d->nx != nx || d->ny != ny || d->nz != nz ||
@@ -1513,7 +1550,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     const double t_start = now_s();
     uint32_t count = 0;
     uint64_t rng;
-    int o, s, attempt, side, im_stored = 0;
+    int o, s, attempt, side, overlap = 0, im_stored = 0;
 
     /* set_im_SIFT3D, sift.c:629-659 */
     d->have_im = 1;
@@ -1543,7 +1580,21 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
      * maximum as it stages it (im_scale, imutil.c:698-713): the scaled image -- read by nothing else -- is
      * not stored (8 B/voxel less; sift3d_amd_copy_level forms it on demand from `last_vol`).  Where the x
      * pass cannot do that (other tap spacings) the image is scaled first, as before. */
+#ifdef SIFT3D_AMD_DIAG
+    /* diagnostic build only (profiles/): 1 = octave 0's last blurs are not held back, 2 = the stages after the
+     * pyramid wait for all of its chains (the schedule of round 4) */
+    const int sched = getenv("SIFT3D_AMD_SCHED") ? atoi(getenv("SIFT3D_AMD_SCHED")) : 0;
+#else
+    const int sched = 0;
+#endif
     d->yz_timed = 0;
+    d->pyr_chains = 0;
+    /* Default configuration on every octave (and a second stream at hand): the stages after the pyramid run
+     * octave 0 on the main stream and the short launches of octaves >= 1 beside it -- in the DoG stage and
+     * again for the extrema sweeps, whose results are then emitted in octave order. */
+    side = !d->cuboid_extrema && d->ngl == 6 && d->num_octaves > 1 && d->num_octaves <= 32 && d->d_work2;
+    for (o = 0; o < d->num_octaves && side; o++)
+        side = (d->odims[o][0] & 3) == 0 && d->odims[o][2] >= 3;
     range_stop(rng);
     rng = range_start("sift3d: Gaussian pyramid");
     sift3d_hip_event_record(d->ev[1], d->stream);
@@ -1583,7 +1634,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                 /* octave 0 up to the source level, then the fork */
                 for (s = 1; s <= ds + 1; s++)
                     if (blur_level(d, d->d_g[s - 1], d->d_g[s], d->odims[0], lu, &d->filt[s], d->stream,
-                                   d->d_tmp_a, d->d_tmp_b, 0, NULL))
+                                   d->d_tmp_a, d->d_tmp_b, s, NULL))
                         return SIFT3D_FAILURE;
                 if (sift3d_hip_event_record(d->ev_fork, d->stream) ||
                     sift3d_hip_stream_wait_event(d->oct_stream, d->ev_fork))
@@ -1599,6 +1650,13 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                  * bandwidth to them.  Octave 1's first levels alone take 0.4 ms; the pyramid's total does
                  * not change (3.47-3.51 against 3.48-3.49 ms), the two large kernels' interference does. */
                 o0_rest = s;     /* (forked: octave 1 exists and reaches the point where they are enqueued) */
+                if (sched & 1) {
+                    for (; o0_rest < d->ngl; o0_rest++)
+                        if (blur_level(d, d->d_g[o0_rest - 1], d->d_g[o0_rest], d->odims[0], lu, &d->filt[o0_rest],
+                                       d->stream, d->d_tmp_a, d->d_tmp_b, o0_rest, NULL))
+                            return SIFT3D_FAILURE;
+                    o0_rest = 0;
+                }
                 continue;
             }
             for (s = 1; s < d->ngl; s++) {
@@ -1615,13 +1673,13 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                     if (o0_rest) {
                         /* ... and now octave 0's last levels, on the main stream */
                         double lu0[3];
-                        int s0;
+                        int s0i;
                         level_units(d, 0, lu0);
                         if (sift3d_hip_stream_wait_event(d->stream, d->ev_oct[o]))
                             return SIFT3D_FAILURE;
-                        for (s0 = o0_rest; s0 < d->ngl; s0++)
-                            if (blur_level(d, d->d_g[s0 - 1], d->d_g[s0], d->odims[0], lu0, &d->filt[s0],
-                                           d->stream, d->d_tmp_a, d->d_tmp_b, s0 == d->ngl - 1, NULL))
+                        for (s0i = o0_rest; s0i < d->ngl; s0i++)
+                            if (blur_level(d, d->d_g[s0i - 1], d->d_g[s0i], d->odims[0], lu0, &d->filt[s0i],
+                                           d->stream, d->d_tmp_a, d->d_tmp_b, s0i, NULL))
                                 return SIFT3D_FAILURE;
                         o0_rest = 0;
                     }
@@ -1630,7 +1688,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                     tb = d->d_tmp3_b;
                 }
                 if (blur_level(d, d->d_g[o * d->ngl + s - 1], d->d_g[o * d->ngl + s], d->odims[o], lu,
-                               &d->filt[s], st, ta, tb, o == 0 && s == d->ngl - 1, NULL)) /* gauss_octave[s], sift.c:689 */
+                               &d->filt[s], st, ta, tb, o == 0 ? s : -1, NULL)) /* gauss_octave[s], sift.c:689 */
                     return SIFT3D_FAILURE;
             }
             if (o != d->num_octaves - 1 && !forked) {
@@ -1640,14 +1698,43 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                     return SIFT3D_FAILURE;
             }
         }
-        if (forked && (sift3d_hip_event_record(d->ev_join, d->oct_stream) ||
-                       sift3d_hip_stream_wait_event(d->stream, d->ev_join) ||
-                       sift3d_hip_event_record(d->ev_join2, d->side_stream) ||
-                       sift3d_hip_stream_wait_event(d->stream, d->ev_join2)))
-            return SIFT3D_FAILURE;
+        if (forked) {
+            /* Round 5: the main stream does NOT wait for the chains of the smaller octaves here.  Octave 0's
+             * DoG maxima and extrema sweep (0.9 ms, device-filling) need octave 0's levels only and start
+             * when its last blur ends; the two side chains wait for EACH OTHER (an octave's levels 4, 5 are
+             * built on the side stream, its first ones on the octave stream) and go on with their own
+             * octaves' DoG maxima and sweeps.  All three meet again before scan + emission. */
+            overlap = side && !pyramid_only && !(sched & 2);
+            d->pyr_chains = 1;
+            if (sift3d_hip_event_record(d->ev_pyr[0], d->oct_stream) ||
+                sift3d_hip_event_record(d->ev_pyr[1], d->side_stream))
+                return SIFT3D_FAILURE;
+            if (overlap) {
+                if (sift3d_hip_stream_wait_event(d->oct_stream, d->ev_pyr[1]) ||
+                    sift3d_hip_stream_wait_event(d->side_stream, d->ev_pyr[0]))
+                    return SIFT3D_FAILURE;
+            } else if (sift3d_hip_stream_wait_event(d->stream, d->ev_pyr[0]) ||
+                       sift3d_hip_stream_wait_event(d->stream, d->ev_pyr[1])) {
+                return SIFT3D_FAILURE;
+            }
+        }
     }
     sift3d_hip_event_record(d->ev[2], d->stream);
     range_stop(rng);
+    if (pyramid_only) {
+        /* sift3d_amd_build_pyramid_device: the Gaussian pyramid alone (bench.py's pyramid-only leg) */
+        for (o = 3; o <= 5; o++)
+            sift3d_hip_event_record(d->ev[o], d->stream);      /* (the later stages: empty) */
+        if (sift3d_hip_stream_sync(d->stream))
+            return SIFT3D_FAILURE;
+        d->have_pyramid = 1;
+        d->im_valid = im_stored;
+        d->last_vol = d_vol == d->d_in ? d_vol : NULL;
+        d->ncand = 0;
+        d->t_pending |= 1;
+        d->t[7] = now_s() - t_start;
+        return SIFT3D_SUCCESS;
+    }
     rng = range_start("sift3d: DoG maxima");
 
     /* build_dog (sift.c:713-732) + the dogmax scan (sift.c:821-826).  Default configuration: only
@@ -1657,11 +1744,8 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     /* Default configuration on every octave (and a second stream at hand): octave 0 on the main
      * stream, the short launches of octaves >= 1 beside it -- in the DoG stage and again for the
      * extrema sweeps, whose results are then emitted in octave order. */
-    side = !d->cuboid_extrema && d->ngl == 6 && d->num_octaves > 1 && d->num_octaves <= 64 && d->d_work2;
-    for (o = 0; o < d->num_octaves && side; o++)
-        side = (d->odims[o][0] & 3) == 0 && d->odims[o][2] >= 3;
-    if (side && (sift3d_hip_event_record(d->ev_fork, d->stream) ||
-                 sift3d_hip_stream_wait_event(d->oct_stream, d->ev_fork)))
+    if (side && !overlap && (sift3d_hip_event_record(d->ev_fork, d->stream) ||
+                             sift3d_hip_stream_wait_event(d->oct_stream, d->ev_fork)))
         return SIFT3D_FAILURE;
     for (o = 0; o < d->num_octaves; o++) {
         const size_t n = (size_t)d->odims[o][0] * d->odims[o][1] * d->odims[o][2];
@@ -1701,8 +1785,10 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                                            d->d_scalars + 8 + o * d->ndl + s, d->stream))
                 return SIFT3D_FAILURE;
     }
+    /* (overlap: the DoG maxima of octaves >= 1 are on the octave stream; the small octaves' sweeps, on the side
+     * stream, wait for them -- the main stream does not) */
     if (side && (sift3d_hip_event_record(d->ev_join, d->oct_stream) ||
-                 sift3d_hip_stream_wait_event(d->stream, d->ev_join)))
+                 sift3d_hip_stream_wait_event(overlap ? d->side_stream : d->stream, d->ev_join)))
         return SIFT3D_FAILURE;
     sift3d_hip_event_record(d->ev[3], d->stream);
     range_stop(rng);
@@ -1724,11 +1810,34 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
             /* three chains: octave 0 | octaves 1, 2 | the small octaves, whose 4-40 us launches (four per
              * octave, each waiting for its predecessor) otherwise queue behind octave 1's sweep and end the
              * stage 0.1 ms after octave 0 has finished */
-            if (sift3d_hip_event_record(d->ev_fork, d->stream) ||
-                sift3d_hip_stream_wait_event(d->oct_stream, d->ev_fork) ||
-                sift3d_hip_stream_wait_event(d->side_stream, d->ev_fork))
+            /* (overlap, first attempt: the side chains are already where they must be and do NOT wait for the
+             * main stream, which may still be inside octave 0's last blur) */
+            if ((!overlap || attempt > 0) &&
+                (sift3d_hip_event_record(d->ev_fork, d->stream) ||
+                 sift3d_hip_stream_wait_event(d->oct_stream, d->ev_fork) ||
+                 sift3d_hip_stream_wait_event(d->side_stream, d->ev_fork)))
                 return SIFT3D_FAILURE;
             for (phase = 1; phase <= 2; phase++) {
+                if (phase == 2) {
+                    /* scan + emission of every octave in two launches (octave order is kept by the scan) */
+                    sift3d_hip_extrema_oct oc[32];
+                    int rc;
+                    for (o = 0; o < d->num_octaves; o++) {
+                        oc[o].d_g = (const float *const *)(d->d_g + o * d->ngl);
+                        oc[o].nx = d->odims[o][0]; oc[o].ny = d->odims[o][1]; oc[o].nz = d->odims[o][2];
+                        oc[o].tag0 = o * d->ngl + 1;
+                        oc[o].d_work = o ? (void *)((char *)d->d_work2 + d->work2_off[o]) : d->d_work;
+                        oc[o].work_bytes = o ? sift3d_hip_extrema_work_bytes(d->odims[o][0], d->odims[o][1],
+                                                                             d->odims[o][2], 3)
+                                             : d->work_bytes;
+                    }
+                    rc = sift3d_hip_extrema_gauss6_finish(oc, d->num_octaves, d->peak_thresh, d->d_cand,
+                                                          d->cand_cap, (uint32_t *)(d->d_scalars + 1), d->stream);
+                    if (rc == SIFT3D_SUCCESS)
+                        break;
+                    if (rc != 1)
+                        return SIFT3D_FAILURE;
+                }
                 for (o = 0; o < d->num_octaves; o++) {
                     void *const xs = phase != 1 || o == 0 ? d->stream : o <= 2 ? d->oct_stream : d->side_stream;
                     void *wk = o ? (void *)((char *)d->d_work2 + d->work2_off[o]) : d->d_work;
@@ -1917,7 +2026,26 @@ int sift3d_amd_detect_keypoints_device(sift3d_detector *d, const float *d_volume
     }
     if (ensure_device(d))
         return SIFT3D_FAILURE;
-    return detect_on_device(d, d_volume, nx, ny, nz, ux, uy, uz, store);
+    return detect_on_device(d, d_volume, nx, ny, nz, ux, uy, uz, store, 0);
+}
+
+/* The Gaussian pyramid alone (max|v|, the scaling folded into the first blur, build_gpyr: sift.c:645-649,
+ * 662-711) of a volume in device memory -- the part of sift3d_amd_detect_keypoints_device that BASELINE's
+ * second metric ("achieved HBM GB/s on the Gauss pyramid") names, for a timed leg of its own: inside a whole
+ * step the pyramid's last launches share the device with octave 0's extrema sweep.  Blocks until the levels
+ * are complete; sift3d_amd_timings()[1] / [6] hold its device time, sift3d_amd_copy_level reads the levels. */
+int sift3d_amd_build_pyramid_device(sift3d_detector *d, const float *d_volume, int nx, int ny, int nz,
+                                    double ux, double uy, double uz)
+{
+    if (!d || !d_volume || nx < 1 || ny < 1 || nz < 1)
+        return SIFT3D_FAILURE;
+    if (!(ux > 0) || !(uy > 0) || !(uz > 0)) {
+        ERR("sift3d_amd: voxel spacing must be positive, provided (%f, %f, %f) \n", ux, uy, uz);
+        return SIFT3D_FAILURE;
+    }
+    if (ensure_device(d))
+        return SIFT3D_FAILURE;
+    return detect_on_device(d, d_volume, nx, ny, nz, ux, uy, uz, NULL, 1);
 }
 
 int sift3d_detect_keypoints(sift3d_detector *const d, const sift3d_image *const im,
@@ -1943,7 +2071,7 @@ int sift3d_detect_keypoints(sift3d_detector *const d, const sift3d_image *const 
     }
     if (sift3d_hip_memcpy_h2d(d->d_in, im->data, n * sizeof(float), d->stream))
         return SIFT3D_FAILURE;
-    return detect_on_device(d, d->d_in, im->nx, im->ny, im->nz, im->ux, im->uy, im->uz, kp);
+    return detect_on_device(d, d->d_in, im->nx, im->ny, im->nz, im->ux, im->uy, im->uz, kp, 0);
 }
 
 int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_store *const kp,

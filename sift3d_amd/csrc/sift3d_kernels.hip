@@ -398,6 +398,63 @@ __global__ __launch_bounds__(256) void k_fir_literal(FirParams P, FirTaps T)
                              P.uhw);
 }
 
+// Filters WIDER than the kernarg tap table (SIFT3D_HIP_MAX_TAPS; the reference accepts any sigma0 >= 0,
+// sift.c:553-565 -- half width ceil(3 sigma), imutil.c:1275-1277): the literal kernel in chunks of taps.  A
+// launch adds taps d in [d_lo, d_hi) to the running sum of every output voxel, which travels between the
+// launches in dst (first chunk: 0); the reference adds the taps of a voxel in ascending d into one float
+// accumulator (imutil.c:791-795), so the chunks reproduce its sum bit for bit.  The interior branch's
+// coordinate round trip (imutil.c:811-817: coord -= step ... coord += step, a state carried from tap to tap)
+// is replayed from d = -hw in every launch -- arithmetic only -- so that its state at a chunk's first tap is
+// the reference's.
+__global__ __launch_bounds__(256) void k_fir_literal_chunk(FirParams P, FirTaps T, int d_lo, int d_hi)
+{
+    const size_t plane = (size_t)P.nx * P.ny;
+    const size_t total = plane * (size_t)(P.z_hi - P.z_lo);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total)
+        return;
+    const int z = P.z_lo + (int)(i / plane);
+    const size_t r = i % plane;
+    const int y = (int)(r / P.nx);
+    const int x = (int)(r % P.nx);
+    const size_t idx = (size_t)z * plane + r;
+    const int p = P.axis == 0 ? x : (P.axis == 1 ? y : z);
+    const size_t stride = P.axis == 0 ? (size_t)1 : (P.axis == 1 ? (size_t)P.nx : plane);
+    const int n_loc = P.axis == 0 ? P.nx : (P.axis == 1 ? P.ny : P.nz);
+    const float *__restrict__ line = P.src + (idx - (size_t)p * stride);
+    const int g = p + P.off, hw = P.hw;
+    const int dim_end = P.n_glob - 1;                             // :753
+    const bool interior = g >= P.uhw && g <= P.n_glob - 2 - P.uhw;  // :762-763, :829
+    float acc = d_lo > -hw ? P.dst[idx] : 0.0f;                   // im_zero, :777
+    float coord = (float)g;
+    for (int d = -hw; d < d_hi; d++) {
+        const float step = (float)d * P.uf;                       // :808 / :837
+        float c;
+        if (interior) {
+            coord -= step;                                        // :811
+            c = coord;
+        } else {
+            c = (float)g - step;                                  // :835,:840
+            if ((int)c < 0)                                       // :843
+                c = -c;
+            else if ((int)c >= dim_end)                           // :846
+                c = 2.0f * (float)dim_end - c - 0.1f;             // :847-848
+        }
+        if (d >= d_lo) {
+            const int lo = (int)c;                                // trunc, :783
+            const float frac = c - (float)lo;                     // :788
+            const int llo = clampi(lo - P.off, 0, n_loc - 1);
+            const int lhi = clampi(lo + 1 - P.off, 0, n_loc - 1);
+            const float a = line[(size_t)llo * stride];
+            const float b = line[(size_t)lhi * stride];
+            acc += T.k[d - d_lo] * ((1.0f - frac) * a + frac * b);    // :791-795
+        }
+        if (interior)
+            coord += step;                                        // :817
+    }
+    P.dst[idx] = acc;
+}
+
 // ---- unit factor 1 (octave 0): edges as a staging transformation ----------------------------
 // With uf == 1 every sample coordinate is an integer, and the reference's edge rules
 // (imutil.c:842-850) depend only on that integer i = x - d, not on (x, d) separately:
@@ -1761,13 +1818,10 @@ __global__ __launch_bounds__(256) void k_extrema_count(const unsigned long long 
 // coalesced), scans them, the thread sums are scanned by wave shifts and the sixteen wave totals by the
 // first wave -- two barriers per chunk (49 152 entries at 512^3: 6 chunks; the chunked Hillis-Steele scan
 // this replaces took 480 barriers and 85 us there).
-__global__ __launch_bounds__(1024) void k_extrema_scan(uint32_t *__restrict__ blk, uint32_t n,
-                                                       uint32_t *__restrict__ d_count)
+__device__ __forceinline__ uint32_t ex_scan_range(uint32_t *__restrict__ blk, uint32_t n, uint32_t carry,
+                                                  uint32_t *wtot, uint32_t &wsum)
 {
-    __shared__ uint32_t wtot[16];
-    __shared__ uint32_t wsum;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    uint32_t carry = *d_count;
     for (uint32_t base = 0; base < n; base += 8192) {
         const uint32_t i0 = base + 8u * (uint32_t)t;
         uint32_t v[8];
@@ -1824,32 +1878,69 @@ __global__ __launch_bounds__(1024) void k_extrema_scan(uint32_t *__restrict__ bl
         }
         __syncthreads();                   // wtot / wsum are rewritten by the next chunk
     }
-    if (t == 0)
+    return carry;
+}
+
+__global__ __launch_bounds__(1024) void k_extrema_scan(uint32_t *__restrict__ blk, uint32_t n,
+                                                       uint32_t *__restrict__ d_count)
+{
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t wsum;
+    const uint32_t carry = ex_scan_range(blk, n, *d_count, wtot, wsum);
+    if (threadIdx.x == 0)
+        *d_count = carry;
+}
+
+// Scan + emission of ALL octaves of a detect call in two launches (round 5; before: a scan and an emission
+// launch per octave, fourteen dependent short launches at 512^3): the octaves' block-count arrays are scanned
+// one after the other by the one workgroup (the running total carries over: octave order), and the emission
+// grid covers every octave's blocks -- a workgroup finds its octave in a table of first-block numbers.
+constexpr int EX_MAX_OCT = 12;
+struct ExOct {
+    const float *g[4];                    // Gaussian levels 1..4: keypoint DoG level i = g[i] - g[i + 1]
+    const unsigned long long *masks;      // [3][nwords]
+    uint32_t *blk;                        // [3][nblk] block counts -> offsets
+    int nx, ny, wpr;
+    uint32_t nwords, nblk;
+    int tag0;
+    uint32_t blk_first;                   // first workgroup (x) of this octave in the emission grid
+};
+struct ExMulti {
+    int n;
+    ExOct o[EX_MAX_OCT];
+};
+
+__global__ __launch_bounds__(1024) void k_extrema_scan_multi(ExMulti M, uint32_t *__restrict__ d_count)
+{
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t wsum;
+    uint32_t carry = *d_count;
+    for (int i = 0; i < M.n; i++)
+        carry = ex_scan_range(M.o[i].blk, M.o[i].nblk * 3u, carry, wtot, wsum);
+    if (threadIdx.x == 0)
         *d_count = carry;
 }
 
 // FROM_G: `cur` and `next` of a level hold the two Gaussian levels whose difference is the DoG
 // level (the DoG pyramid is not stored)
+// one emission workgroup: block `bx` of a level (masks / blk_off: that level's own arrays)
 template <bool FROM_G>
-__global__ __launch_bounds__(256) void k_extrema_emit(ExLevels LV, ExGeom E,
-                                                      const unsigned long long *__restrict__ masks,
-                                                      const uint32_t *__restrict__ blk_off,
-                                                      sift3d_hip_cand *__restrict__ out,
-                                                      uint32_t cap)
+__device__ __forceinline__ void ex_emit_block(const float *__restrict__ cur, const float *__restrict__ next,
+                                              int tag, int nx, int ny, int wpr, uint32_t nwords, uint32_t bx,
+                                              const unsigned long long *__restrict__ masks,
+                                              const uint32_t *__restrict__ blk_off,
+                                              sift3d_hip_cand *__restrict__ out, uint32_t cap)
 {
     __shared__ uint32_t pre[EX_WPB + 1];
-    const int level = blockIdx.y;
-    const sift3d_hip_extrema_level L = LV.lv[level];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t w0 = blockIdx.x * EX_WPB;
+    const uint32_t w0 = bx * EX_WPB;
     // pre[i] = candidates in the block's words before word i: the first EX_WPB / 64 waves hold one word per
     // lane, scan their counts by wave shifts and add the totals of the waves before them
     static_assert(EX_WPB % 64 == 0 && EX_WPB <= 256, "one word per thread of the first waves");
     __shared__ uint32_t wtot[EX_WPB / 64];
     {
         const uint32_t word = w0 + threadIdx.x;
-        uint32_t inc = threadIdx.x < EX_WPB && word < E.nwords
-                           ? (uint32_t)__popcll(masks[(size_t)level * E.nwords + word]) : 0;
+        uint32_t inc = threadIdx.x < EX_WPB && word < nwords ? (uint32_t)__popcll(masks[word]) : 0;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t v = __shfl_up(inc, o, 64);
@@ -1873,13 +1964,13 @@ __global__ __launch_bounds__(256) void k_extrema_emit(ExLevels LV, ExGeom E,
     }
     if (pre[EX_WPB] == 0)
         return;
-    const uint32_t base = blk_off[(size_t)level * E.nblk + blockIdx.x];
-    const size_t ys = E.nx, zs = (size_t)E.nx * E.ny;
+    const uint32_t base = blk_off[bx];
+    const size_t ys = nx, zs = (size_t)nx * ny;
     // the wave's EX_WPB / 4 (<= 64) mask words: one load, lane i holds word i
     static_assert(EX_WPB / 4 <= 64, "one word per lane");
     unsigned long long mine = 0ull;
-    if (lane < EX_WPB / 4 && w0 + wave * (EX_WPB / 4) + lane < E.nwords)
-        mine = masks[(size_t)level * E.nwords + w0 + wave * (EX_WPB / 4) + lane];
+    if (lane < EX_WPB / 4 && w0 + wave * (EX_WPB / 4) + lane < nwords)
+        mine = masks[w0 + wave * (EX_WPB / 4) + lane];
     // only the words that hold a candidate (a few per cent of them) are visited
     unsigned long long todo = __ballot(mine != 0ull);
     while (todo) {
@@ -1895,15 +1986,41 @@ __global__ __launch_bounds__(256) void k_extrema_emit(ExLevels LV, ExGeom E,
         const uint32_t pos = base + pre[wi] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         if (pos >= cap)
             continue;
-        const uint32_t row = word / E.wpr;
-        const int x = (int)(word % E.wpr) * 64 + lane;
-        const size_t p = (size_t)x + ys * (row % E.ny) + zs * (row / E.ny);
+        const uint32_t row = word / wpr;
+        const int x = (int)(word % wpr) * 64 + lane;
+        const size_t p = (size_t)x + ys * (row % ny) + zs * (row / ny);
         sift3d_hip_cand c;
         c.idx = (uint32_t)p;
-        c.tag = L.tag;
-        c.val = fabsf(FROM_G ? L.cur[p] - L.next[p] : L.cur[p]);     // sift.c:864
+        c.tag = tag;
+        c.val = fabsf(FROM_G ? cur[p] - next[p] : cur[p]);     // sift.c:864
         out[pos] = c;
     }
+}
+
+template <bool FROM_G>
+__global__ __launch_bounds__(256) void k_extrema_emit(ExLevels LV, ExGeom E,
+                                                      const unsigned long long *__restrict__ masks,
+                                                      const uint32_t *__restrict__ blk_off,
+                                                      sift3d_hip_cand *__restrict__ out,
+                                                      uint32_t cap)
+{
+    const int level = blockIdx.y;
+    const sift3d_hip_extrema_level L = LV.lv[level];
+    ex_emit_block<FROM_G>(L.cur, L.next, L.tag, E.nx, E.ny, E.wpr, E.nwords, blockIdx.x,
+                          masks + (size_t)level * E.nwords, blk_off + (size_t)level * E.nblk, out, cap);
+}
+
+__global__ __launch_bounds__(256) void k_extrema_emit_multi(ExMulti M, sift3d_hip_cand *__restrict__ out,
+                                                            uint32_t cap)
+{
+    int i = 0;                            // (wave-uniform: blockIdx only)
+    while (i + 1 < M.n && blockIdx.x >= M.o[i + 1].blk_first)
+        i++;
+    const ExOct &O = M.o[i];
+    const int level = blockIdx.y;
+    ex_emit_block<true>(O.g[level], O.g[level + 1], O.tag0 + level, O.nx, O.ny, O.wpr, O.nwords,
+                        blockIdx.x - O.blk_first, O.masks + (size_t)level * O.nwords,
+                        O.blk + (size_t)level * O.nblk, out, cap);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -3024,7 +3141,7 @@ static int fir_impl(const sift3d_hip_fir_args *a, const float *d_scale_max, void
 {
     hipStream_t st = (hipStream_t)stream;
     if (!a || !a->src || !a->dst || a->nx < 1 || a->ny < 1 || a->nz < 1 || a->axis < 0 ||
-        a->axis > 2 || a->width < 1 || !(a->width & 1) || a->width > SIFT3D_HIP_MAX_TAPS ||
+        a->axis > 2 || a->width < 1 || !(a->width & 1) || a->width > (1 << 20) ||
         a->z_lo < 0 || a->z_hi > a->nz || a->src == a->dst) {
         snprintf(g_err, sizeof(g_err), "sift3d_hip_fir: invalid arguments");
         fprintf(stderr, "sift3d_amd: %s\n", g_err);
@@ -3035,7 +3152,7 @@ static int fir_impl(const sift3d_hip_fir_args *a, const float *d_scale_max, void
     FirParams P;
     FirTaps T;
     memset(&T, 0, sizeof(T));
-    memcpy(T.k, a->taps, sizeof(float) * a->width);
+    memcpy(T.k, a->taps, sizeof(float) * (a->width < SIFT3D_HIP_MAX_TAPS ? a->width : SIFT3D_HIP_MAX_TAPS));
     P.src = a->src; P.dst = a->dst;
     P.nx = a->nx; P.ny = a->ny; P.nz = a->nz;
     P.axis = a->axis;
@@ -3054,6 +3171,18 @@ static int fir_impl(const sift3d_hip_fir_args *a, const float *d_scale_max, void
         return SIFT3D_FAILURE;
     }
     const size_t plane = (size_t)a->nx * a->ny;
+    if (a->width > SIFT3D_HIP_MAX_TAPS) {
+        // wider than the tap tables of the fast kernels: the literal kernel, SIFT3D_HIP_MAX_TAPS taps per launch
+        const size_t total = plane * (size_t)(a->z_hi - a->z_lo);
+        for (int d_lo = -P.hw; d_lo <= P.hw; d_lo += SIFT3D_HIP_MAX_TAPS) {
+            const int d_hi = d_lo + SIFT3D_HIP_MAX_TAPS < P.hw + 1 ? d_lo + SIFT3D_HIP_MAX_TAPS : P.hw + 1;
+            memcpy(T.k, a->taps + (d_lo + P.hw), sizeof(float) * (size_t)(d_hi - d_lo));
+            hipLaunchKernelGGL(k_fir_literal_chunk, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P, T,
+                               d_lo, d_hi);
+        }
+        LAUNCH_CHECK();
+        return SIFT3D_SUCCESS;
+    }
     int shift = 0;
     const bool dyadic = is_dyadic(P.uf, &shift) && shift <= 12 && P.n_glob < (1 << (23 - shift));
     const bool aligned = (((uintptr_t)a->src | (uintptr_t)a->dst) & 15) == 0;
@@ -3522,6 +3651,47 @@ static int extrema_gauss6_impl(const float *const *d_g, const float *d_absmax, c
     }
     hipLaunchKernelGGL(k_extrema_emit<true>, dim3(E.nblk, 3), dim3(256), 0, st, LV, E, masks, blk, d_out,
                        cap);
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
+}
+
+// Phase 2 of sift3d_hip_extrema_gauss6_[est_]phase for ALL octaves of a call at once: one scan launch over the
+// octaves' block counts in order, one emission launch over every octave's blocks; appends at *d_count in
+// (octave, level, z, y, x) order -- the reference's (sift.c:835-868).  1: more octaves than one launch takes
+// (the caller then issues phase 2 per octave).
+int sift3d_hip_extrema_gauss6_finish(const sift3d_hip_extrema_oct *octs, int n_oct, double peak_thresh,
+                                     sift3d_hip_cand *d_out, uint32_t cap, uint32_t *d_count, void *stream)
+{
+    if (n_oct < 1 || n_oct > EX_MAX_OCT)
+        return 1;
+    ExMulti M;
+    memset(&M, 0, sizeof(M));
+    M.n = n_oct;
+    uint32_t nb = 0;
+    for (int i = 0; i < n_oct; i++) {
+        const sift3d_hip_extrema_oct &q = octs[i];
+        if ((size_t)q.nx * q.ny * q.nz >= (1ull << 32) ||
+            q.work_bytes < sift3d_hip_extrema_work_bytes(q.nx, q.ny, q.nz, 3)) {
+            snprintf(g_err, sizeof(g_err), "sift3d_hip_extrema_gauss6_finish: invalid arguments");
+            fprintf(stderr, "sift3d_amd: %s\n", g_err);
+            return SIFT3D_FAILURE;
+        }
+        const ExGeom E = ex_geom(q.nx, q.ny, q.nz, peak_thresh, 0);
+        ExOct &O = M.o[i];
+        for (int k = 0; k < 4; k++)
+            O.g[k] = q.d_g[k + 1];
+        unsigned long long *masks = reinterpret_cast<unsigned long long *>(q.d_work);
+        O.masks = masks;
+        O.blk = reinterpret_cast<uint32_t *>(masks + (size_t)3 * E.nwords);
+        O.nx = q.nx; O.ny = q.ny; O.wpr = E.wpr;
+        O.nwords = E.nwords; O.nblk = E.nblk;
+        O.tag0 = q.tag0;
+        O.blk_first = nb;
+        nb += E.nblk;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_extrema_scan_multi, dim3(1), dim3(1024), 0, st, M, d_count);
+    hipLaunchKernelGGL(k_extrema_emit_multi, dim3(nb, 3), dim3(256), 0, st, M, d_out, cap);
     LAUNCH_CHECK();
     return SIFT3D_SUCCESS;
 }

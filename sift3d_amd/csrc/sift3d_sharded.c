@@ -273,8 +273,7 @@ sift3d_amd_sharded *sift3d_amd_sharded_create(int nx, int ny, int nz, const sift
     for (i = 0; i < S->ngl; i++) {
         const double s_cur = i == 0 ? S->sigma_n : S->sigma0 * pow(2.0, (double)(i - 2) / S->K);
         const double s_next = S->sigma0 * pow(2.0, (double)(i - 1) / S->K);
-        if (gauss_filter(&S->filt[i], sqrt(s_next * s_next - s_cur * s_cur)) ||
-            S->filt[i].width > SIFT3D_HIP_MAX_TAPS)
+        if (gauss_filter(&S->filt[i], sqrt(s_next * s_next - s_cur * s_cur)))
             goto fail;
         if (S->filt[i].width / 2 > hw_max)
             hw_max = S->filt[i].width / 2;

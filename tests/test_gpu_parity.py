@@ -138,6 +138,39 @@ def test_fir_fast_paths_vs_oracle(gpu, oracle_mod, shape):
                                               % (sigma, uf, ax))
 
 
+def test_fir_wider_than_the_tap_tables_vs_oracle(gpu, oracle_mod):
+    """Filters of more than SIFT3D_HIP_MAX_TAPS = 65 taps (sigma0 above ~7: the reference accepts any sigma0,
+    sift.c:553-565, half width ceil(3 sigma), imutil.c:1275-1277) take the literal kernel in chunks of 65 taps,
+    the running sums carried in dst: bit-identical to the oracle for every axis, unit spacing, dyadic and
+    non-dyadic tap spacings (the interior branch's coordinate round trip, imutil.c:811-817), axes SHORTER than
+    the filter, and as Z-slabs."""
+    api, hip, torch = gpu
+    rng = np.random.default_rng(77)
+    vol = rng.standard_normal((41, 90, 100)).astype(np.float32)
+    ran = 0
+    for sigma in (11.0, 12.26, 25.0, 44.0):          # 67, 75, 151 (three chunks), 265 taps
+        taps = oracle_mod.gauss_taps(sigma)
+        assert len(taps) > 65 and len(taps) == 2 * int(np.ceil(3 * sigma)) + 1
+        for uf in (1.0, 0.5, 0.125, 1.0 / 1.5, 1.0 / 0.7):
+            for ax in range(3):
+                if (len(taps) // 2) * uf > vol.shape[2 - ax] - 2:
+                    continue        # a mirrored sample would leave the row: undefined in the reference too
+                want, r = oracle_mod.fir_axis(vol, taps, ax, uf=np.float32(uf), mode=0)
+                assert r == 0
+                got = _fir_gpu(hip, torch, vol, taps, ax, np.float32(uf))
+                np.testing.assert_array_equal(got, want, err_msg="sigma %g uf %g axis %d" % (sigma, uf, ax))
+                ran += 1
+    assert ran >= 36
+    # a Z-slab of the volume (planes 10 .. 30 of 41; outputs 16 .. 24: the taps reach 37 / 8 + 1 planes) under
+    # the 75-tap filter at spacing 1/8
+    taps = oracle_mod.gauss_taps(12.26)
+    want, r = oracle_mod.fir_axis(vol, taps, 2, uf=np.float32(0.125), mode=0)
+    src = torch.from_numpy(vol[10:30].copy()).cuda()
+    dst = torch.full(src.shape, float("nan"), device="cuda")
+    hip.fir(src, dst, 2, taps, unit_factor=0.125, n_glob=41, off=10, z_lo=6, z_hi=14)
+    np.testing.assert_array_equal(dst.cpu().numpy()[6:14], want[16:24])
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 512), (1, 3, 1024), (2, 2, 512), (1, 17, 1536)])
 def test_fir_x_few_rows(gpu, oracle_mod, shape):
     """The x pass with whole 512-float segments (k_fir_x_u1f) on volumes with fewer rows than one wave takes."""
@@ -280,7 +313,7 @@ def _run_api(api, vol, units=(1, 1, 1), params=None, device_input=False):
 
 @pytest.mark.parametrize("name", ["g3_64", "g3_70x50x41", "g3_aniso", "g3_params",
                                   "g3_lattice48", "g5_128", "g3_cuboid64", "g3_cuboid_params",
-                                  "g3_sigma3", "g3_sigma5", "g3_switch285", "g3_switch_aniso"])
+                                  "g3_sigma3", "g3_sigma5", "g3_switch285", "g3_switch_aniso", "g3_sigma8"])
 def test_detect_describe_golden(gpu, oracle_mod, name):
     """Against the reference's own outputs: every pyramid level (sha1 digests + small levels
     in full), candidate count, the keypoint list incl. the stale-strength quirk, R,
@@ -331,6 +364,12 @@ def test_detect_describe_golden(gpu, oracle_mod, name):
     m2 = desc2.to_mat_rm()
     np.testing.assert_array_equal(m2[idx, 3:] + np.float32(0), g["desc_hist"] + np.float32(0))
     assert util.assert_desc_projection(m2[:, 3:], g["desc_proj"], rtol=1e-12) < 1e-12
+    if name == "g3_sigma8":
+        # sigma0 = 8: Gaussian filters of 31 ... 75 taps (the last one wider than SIFT3D_HIP_MAX_TAPS: the chunked
+        # literal kernel) -- every level digest above is the reference's; the windows hold the whole volume
+        assert max(len(t) for t in (api.gauss_filter(sg) for sg in
+                                    (12.26, 9.73))) > 65
+        np.testing.assert_array_equal(m, m2)
     if name in ("g3_sigma3", "g3_sigma5"):
         # windows of 2e5 .. 4e6 voxels: the automatic mode has taken the reference-order kernel for them
         np.testing.assert_array_equal(m, m2)

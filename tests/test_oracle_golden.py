@@ -14,7 +14,8 @@ from tests import util
 
 E2E = ["g3_64", "g3_70x50x41", "g3_aniso", "g3_params", "g3_lattice48", "g3_cuboid64",
        "g3_cuboid_params",   # the last two: CUBOID_EXTREMA build of the reference (sift.c:24)
-       "g3_sigma3", "g3_sigma5", "g3_switch285", "g3_switch_aniso"]   # wide windows (sift.c:1453-1456): a bin receives ~7x / ~30x the terms
+       "g3_sigma3", "g3_sigma5", "g3_switch285", "g3_switch_aniso",
+       "g3_sigma8"]                # octave filters of 31 ... 75 taps   # wide windows (sift.c:1453-1456): a bin receives ~7x / ~30x the terms
 BIG = [n for n in ("g5_128",) if util.have(n)]
 
 
