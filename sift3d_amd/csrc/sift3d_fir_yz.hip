@@ -7,8 +7,6 @@
 // without it).  Numerical contract and citations as in sift3d_kernels.hip.
 #include "sift3d_kernels_common.h"
 
-#include <cstdlib>
-
 // ---- fused y + z passes, unit factor 1 -------------------------------------------------------
 // dst = FIR_z(FIR_y(src)) without the y-pass result ever reaching HBM.  A workgroup owns a
 // 4*TXQ(x) x TY(y) column of the volume (64 x 32 or 128 x 32) and sweeps a segment along z.  For every plane it stages
@@ -237,14 +235,7 @@ __global__ __launch_bounds__(TXQ * TY) __attribute__((amdgpu_waves_per_eu(4, 4))
 // the two staged rows they interpolate, by the workgroups of the last tile row only (one more barrier
 // there); virtual planes of the high z face from two y-filtered planes, as before.  Arithmetic and tap
 // order are those of the separate passes: bit-identical results.
-// R2 (round 5): a thread computes TWO adjacent rows of a column of two x (a float2 each) instead of one row
-// of four x.  The y filter is what the wide instances spend their LDS bandwidth on -- W 16-byte tile reads per
-// output quad --, and the windows of two adjacent rows overlap in all but one row: the thread streams the W + 1
-// tile rows from the highest down, one 8-byte read each, and every row feeds both outputs (tap j of the upper
-// row, tap j - 1 of the lower one: ascending d for each, the reference's order).  Half the LDS read bytes per
-// output, the same arithmetic, and the same registers: the two float2 results travel as one float4 through
-// the z ring (the z filter is componentwise).
-template <int HW, int TY, bool R2>
+template <int HW, int TY>
 __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fir_yz_dma(FirParams P, FirTaps T, EdgeTab Ey, EdgeTab Ez)
 {
     constexpr int TXQ = 16, W = 2 * HW + 1, ROWS = TY + 2 * HW, ROWS4 = (ROWS + 3) & ~3, NB = 4;
@@ -255,17 +246,13 @@ __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
     __shared__ int seq[SEQ + 1];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int qx = tid % TXQ;
-    // this thread's outputs: R2: rows ty, ty + 1 of the float2 column cx (tile rows are 2 TXQ float2 long);
-    // else row ty of the float4 column qx
-    const int cx = R2 ? tid % (2 * TXQ) : qx;
-    const int ty = R2 ? 2 * (tid / (2 * TXQ)) : tid / TXQ;
-    const int x = R2 ? blockIdx.x * TXQ * 4 + 2 * cx : (blockIdx.x * TXQ + qx) * 4;
+    const int qx = tid % TXQ, ty = tid / TXQ;
+    const int x = (blockIdx.x * TXQ + qx) * 4;
     const int y0 = blockIdx.y * TY;
     const int y = y0 + ty;
     const int nx = P.nx, ny = P.ny;
     const size_t plane = (size_t)nx * ny;
-    const bool writer = x < nx && y + (R2 ? 1 : 0) < ny;
+    const bool writer = x < nx && y < ny;
     const int nl1 = P.nz - 1;
     const int off = P.off, endz = P.n_glob - 1, endy = ny - 1;
     const int p0 = P.z_lo + blockIdx.z * P.ts;
@@ -339,10 +326,7 @@ __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
         case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
         case 5: asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)\n\ts_barrier" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory"); break;
         }
     };
     // does this wave issue a store per output plane at all (else it must not count them)
@@ -371,7 +355,7 @@ __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
     // y-filtered value of this thread's column for the next request of the list
     auto yfilt = [&]() -> float4 {
         // younger than the pieces of request t: those of t + 1 and t + 2, and this wave's recent stores
-        wait_barrier(2 * nd + (R2 ? 2 : 1) * __builtin_popcount(shist));     // (R2: two stores per plane)
+        wait_barrier(2 * nd + __builtin_popcount(shist));
         stage(t + NB - 1);
         const int b = t & (NB - 1);
         if (yedge) {
@@ -382,27 +366,9 @@ __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (R2) {
-            // (x, y): row ty, (z, w): row ty + 1; tile row ty + 1 + 2 HW - j feeds tap j of the upper row
-            // (d = j - HW) and tap j - 1 of the lower one
-            const float2 *trow = reinterpret_cast<const float2 *>(&tile[b][0][0]) + cx;
 #pragma unroll
-            for (int j = 0; j <= W; j++) {
-                const float2 v = trow[(ty + 1 + 2 * HW - j) * (2 * TXQ)];
-                if (j < W) {
-                    acc.z += T.k[j] * v.x;
-                    acc.w += T.k[j] * v.y;
-                }
-                if (j >= 1) {
-                    acc.x += T.k[j - 1] * v.x;
-                    acc.y += T.k[j - 1] * v.y;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int dd = -HW; dd <= HW; dd++)
-                Vec<4>::mac(acc, T.k[dd + HW], tile[b][ty + HW - dd][qx]);
-        }
+        for (int dd = -HW; dd <= HW; dd++)
+            Vec<4>::mac(acc, T.k[dd + HW], tile[b][ty + HW - dd][qx]);
         t++;
         return acc;
     };
@@ -456,14 +422,8 @@ __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
                 for (int dd = -HW; dd <= HW; dd++)
                     Vec<4>::mac(acc, T.k[dd + HW], ring[(j + HW - dd) % W]);   // E[q - d], d ascending
-                if (writer) {
-                    if (R2) {
-                        *reinterpret_cast<float2 *>(d + (size_t)q * plane) = make_float2(acc.x, acc.y);
-                        *reinterpret_cast<float2 *>(d + (size_t)q * plane + nx) = make_float2(acc.z, acc.w);
-                    } else {
-                        st4(d + (size_t)q * plane, acc);
-                    }
-                }
+                if (writer)
+                    st4(d + (size_t)q * plane, acc);
             }
         }
     }
@@ -472,10 +432,6 @@ __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// half widths whose k_fir_yz_dma instance computes two rows per thread (bit HW); measured per instance
-#ifndef YZ_R2_MASK
-#define YZ_R2_MASK 0
-#endif
 template <int HW>
 static void launch_fir_yz(const FirParams &P, const FirTaps &T, const EdgeTab &Ey, const EdgeTab &Ez,
                           int ty, hipStream_t st)
@@ -492,15 +448,7 @@ static void launch_fir_yz(const FirParams &P, const FirTaps &T, const EdgeTab &E
         // 64-row one stages fewer halo rows per output row
         constexpr int DTY = HW <= 2 ? 64 : 32;
         dim3 grid(P.nx / 64, P.ny / DTY, nseg);
-#ifdef SIFT3D_AMD_DIAG
-        static const int r2mask = getenv("SIFT3D_AMD_YZR2") ? atoi(getenv("SIFT3D_AMD_YZR2")) : YZ_R2_MASK;
-#else
-        const int r2mask = YZ_R2_MASK;
-#endif
-        if ((r2mask >> HW) & 1)
-            hipLaunchKernelGGL((k_fir_yz_dma<HW, DTY, true>), grid, dim3(16 * DTY), 0, st, P, T, Ey, Ez);
-        else
-            hipLaunchKernelGGL((k_fir_yz_dma<HW, DTY, false>), grid, dim3(16 * DTY), 0, st, P, T, Ey, Ez);
+        hipLaunchKernelGGL((k_fir_yz_dma<HW, DTY>), grid, dim3(16 * DTY), 0, st, P, T, Ey, Ez);
     } else if ((P.nx & 63) == 0 && P.ny >= 128) {
         dim3 grid((P.nx / 4 + 15) / 16, (P.ny + 63) / 64, nseg);
         hipLaunchKernelGGL((k_fir_yz_u1<HW, 64, 16>), grid, dim3(1024), 0, st, P, T, Ey, Ez);
