@@ -2114,24 +2114,46 @@ __device__ __forceinline__ void orient_serial(const sift3d_hip_level *__restrict
 
     // 64 queued (in-sphere) voxels: their nine terms in parallel, then added in voxel order by
     // the nine accumulator lanes.  Lanes beyond `cnt` contribute exact zeros (a no-op).
-    auto batch = [&](int cnt) {
-        const bool in = lane < cnt;
-        float gx = 0.f, gy = 0.f, gz = 0.f, w = 0.f;
-        if (in) {
-            const int pk = queue[(qhead + lane) & 255];
+    // The six gradient samples of a batch are REQUESTED one batch ahead (round 5): a batch's serial chain is
+    // ~0.3 us of dependent adds, its samples come from L2 / HBM in ~2 us -- requested where they were needed,
+    // every batch of the longest window exposed that latency in full, and k_orient_fix lasts as long as its
+    // longest window.  request(): the samples and the weight of the batch at queue position `from` into
+    // registers; batch(): terms and sums from the registers of an earlier request.
+    struct Req {
+        float s[6], w;
+    };
+    auto request = [&](uint32_t from, int cnt, Req &q) {
+        q.w = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            q.s[k] = 0.f;
+        if (lane < cnt) {
+            const int pk = queue[(from + lane) & 255];
             const int x = B.xs + (pk & 1023), y = B.ys + ((pk >> 10) & 1023), z = B.zs + (pk >> 20);
             if (use_lut) {
                 const int i = x - kx, j = y - ky, l = z - kz;
-                w = wlut[min(i * i + j * j + l * l, WLUT - 1)];   // (in-sphere: k <= rad^2 / u^2)
+                q.w = wlut[min(i * i + j * j + l * l, WLUT - 1)];   // (in-sphere: k <= rad^2 / u^2)
             } else {
                 const float dx = ((float)x - cx) * L.ux;          // sift.c:102-104
                 const float dy = ((float)y - cy) * L.uy;
                 const float dz = ((float)z - cz) * L.uz;
                 const float sq = dx * dx + dy * dy + dz * dz;     // sift.c:105
-                w = s3d_expf((float)(-0.5 * (double)sq / sig2));  // sift.c:972
+                q.w = s3d_expf((float)(-0.5 * (double)sq / sig2));  // sift.c:972
             }
-            grad_iso(L, x, y, z - L.z_off, gx, gy, gz);
+            const size_t ys = L.nx, zs = (size_t)L.nx * L.ny;
+            const float *p = L.data + (size_t)x + ys * y + zs * (z - L.z_off);
+            q.s[0] = p[1]; q.s[1] = *(p - 1); q.s[2] = p[ys]; q.s[3] = *(p - ys);
+            q.s[4] = p[zs]; q.s[5] = *(p - zs);
         }
+    };
+    auto batch = [&](int cnt, const Req &q) {
+        const bool in = lane < cnt;
+        // IM_GET_GRAD_ISO (sift.c:140-145, immacros.h:105-111), as grad_iso()
+        float gx = 0.5f * (q.s[0] - q.s[1]), gy = 0.5f * (q.s[2] - q.s[3]), gz = 0.5f * (q.s[4] - q.s[5]);
+        gx *= 1.0f / L.ux;
+        gy *= 1.0f / L.uy;
+        gz *= 1.0f / L.uz;
+        const float w = q.w;
         // sift.c:978-987
         td[0][lane] = in ? (double)gx * (double)gx * (double)w : 0.0;
         td[1][lane] = in ? (double)gx * (double)gy * (double)w : 0.0;
@@ -2166,6 +2188,9 @@ __device__ __forceinline__ void orient_serial(const sift3d_hip_level *__restrict
     // rectangle of each plane's disc is scanned; the exact per-voxel test (sift.c:106) and the scan
     // order are unchanged.
     const float rad2f = (float)rad2;
+    Req preq;                 // the batch whose samples are in flight (or have arrived)
+    bool pend = false;
+    request(0, 0, preq);
     for (int z = B.zs; z <= B.ze; z++) {
         const float dz = ((float)z - cz) * L.uz;
         const float rz = sqrtf(fmaxf(rad2f - dz * dz, 0.0f)) * 1.001f;
@@ -2205,13 +2230,27 @@ __device__ __forceinline__ void orient_serial(const sift3d_hip_level *__restrict
             qtail += (uint32_t)__popcll(m);
             __syncthreads();
             if (qtail - qhead >= 64) {
-                batch(64);
+                // the new batch's samples are requested, THEN the batch before it is summed
+                Req nreq;
+                request(qhead, 64, nreq);
+                if (pend)
+                    batch(64, preq);
+                preq = nreq;
+                pend = true;
                 qhead += 64;
             }
         }
     }
-    if (qtail != qhead)
-        batch((int)(qtail - qhead));
+    {
+        const int rest = (int)(qtail - qhead);
+        Req nreq;
+        if (rest)
+            request(qhead, rest, nreq);
+        if (pend)
+            batch(64, preq);
+        if (rest)
+            batch(rest, nreq);
+    }
     // gather the nine sums on every lane (uniform epilogue, no divergence)
     double A[9];
     A[0] = __shfl(dacc, 0, 64); A[1] = __shfl(dacc, 1, 64); A[2] = __shfl(dacc, 2, 64);
