@@ -2048,11 +2048,25 @@ __device__ __forceinline__ void grad_iso(const sift3d_hip_level &L, int x, int y
 // order by nine accumulator lanes (six double structure-tensor sums, three float gradient
 // sums), which makes every sum bit-identical to the serial CPU loop.
 // ---------------------------------------------------------------------------------------
+// Lanes of ONE wave exchanging data through LDS: the DS operations of a wave execute in issue order, so a read
+// issued after a write sees it -- no s_waitcnt, no s_barrier; the fences only keep the compiler from moving
+// LDS accesses across the hand-over point (as wave_sync() in sift3d_describe.hip).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ void orient_serial(const sift3d_hip_level *__restrict__ levels,
                                               const sift3d_hip_cand *__restrict__ cand, uint32_t ci,
                                               double corner_thresh, float *__restrict__ Rout,
                                               int32_t *__restrict__ keep)
 {
+    // (ONE wave per workgroup -- k_orient, k_orient_fix: the hand-overs through LDS below are between lanes of
+    // that wave, whose DS operations execute in issue order: wave_lds_sync() only stops the compiler from
+    // moving LDS accesses across them.  A workgroup barrier here would also drain the wave's vector-memory
+    // queue -- s_waitcnt vmcnt(0) -- i.e. wait for the samples just requested for the NEXT batch.)
     // rows padded by 16 bytes: the accumulator lanes' 16-byte reads fall on different banks
     __shared__ __attribute__((aligned(16))) double td[6][66];
     __shared__ __attribute__((aligned(16))) float tf[3][68];
@@ -2110,7 +2124,7 @@ __device__ __forceinline__ void orient_serial(const sift3d_hip_level *__restrict
             }
         }
     }
-    __syncthreads();
+    wave_lds_sync();
 
     // 64 queued (in-sphere) voxels: their nine terms in parallel, then added in voxel order by
     // the nine accumulator lanes.  Lanes beyond `cnt` contribute exact zeros (a no-op).
@@ -2164,7 +2178,7 @@ __device__ __forceinline__ void orient_serial(const sift3d_hip_level *__restrict
         tf[0][lane] = in ? gx * w : 0.0f;
         tf[1][lane] = in ? gy * w : 0.0f;
         tf[2][lane] = in ? gz * w : 0.0f;
-        __syncthreads();
+        wave_lds_sync();
         // The nine accumulator lanes run both serial sums (the double and the float chain
         // interleave and hide each other's latency; only lanes 0..5 / 6..8 hold meaningful rows).
         // The other lanes are masked off, and one pair of 16-byte reads serves both kinds of
@@ -2181,7 +2195,7 @@ __device__ __forceinline__ void orient_serial(const sift3d_hip_level *__restrict
                 dacc += __hiloint2double((int)u1.w, (int)u1.z); facc += __uint_as_float(u0.w);
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     };
 
     // Only the (conservative: +0.1 %, against float error of at most 1e-5 relative) bounding
@@ -2228,7 +2242,7 @@ __device__ __forceinline__ void orient_serial(const sift3d_hip_level *__restrict
             if (in)
                 queue[(qtail + (uint32_t)__popcll(m & lt_mask)) & 255] = pk;
             qtail += (uint32_t)__popcll(m);
-            __syncthreads();
+            wave_lds_sync();
             if (qtail - qhead >= 64) {
                 // the new batch's samples are requested, THEN the batch before it is summed
                 Req nreq;
