@@ -20,7 +20,7 @@ SIFT3D_SUCCESS = 0
 SIFT3D_FAILURE = -1
 SIFT3D_DOUBLE, SIFT3D_FLOAT, SIFT3D_INT = 0, 1, 2
 TIMED_BLURS = 8
-NUM_TIMINGS = 10 + 2 * TIMED_BLURS
+NUM_TIMINGS = 10 + 2 * TIMED_BLURS + 2
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -391,7 +391,9 @@ class Detector:
         p = lib().sift3d_amd_timings(self.h)
         names = ("scale", "gauss", "dog", "extrema", "orient", "describe", "gauss_dev",
                  "detect_wall", "describe_wall", "yz_last")
-        return dict(zip(names, [p[i] for i in range(len(names))]))
+        out = dict(zip(names, [p[i] for i in range(len(names))]))
+        out["detect_dev"] = p[10 + 2 * TIMED_BLURS]       # first to last stage event of detect
+        return out
 
     def describe_clock(self):
         """(shader cycles, seconds) of the fast descriptor kernel of the last extract_descriptors, measured by

@@ -1271,6 +1271,7 @@ const double *sift3d_amd_timings(const sift3d_detector *dc)
                 last = b;
         }
         d->t[9] = last >= 0 ? d->t[10 + SIFT3D_AMD_TIMED_BLURS + last] : 0.0;
+        d->t[10 + 2 * SIFT3D_AMD_TIMED_BLURS] = stage_seconds(d->ev[0], d->ev[5]);
     }
     if (d->t_pending & 2)
         d->t[5] = stage_seconds(d->ev[6], d->ev[7]);
