@@ -758,3 +758,44 @@ def test_scaled_image_is_not_formed_from_a_borrowed_pointer(gpu, oracle_mod):
     np.testing.assert_array_equal(det.level(0, 0, -1).shape, (48, 48, 48))   # the pyramid itself stays readable
     assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
     np.testing.assert_array_equal(det.level(2, 0, 0), want)
+
+
+def test_pyramid_only_entry_and_launch_timings(gpu, oracle_mod):
+    """sift3d_amd_build_pyramid_device (bench.py's pyramid-only leg) builds exactly the pyramid of a detect call;
+    the per-launch timings of octave 0 (sift3d_amd_timings [10..]: HIP events around every x and fused y+z launch)
+    are filled for the blurs that took the fused kernel, and the descriptor kernel's own clock probe reads a
+    plausible shader clock."""
+    api, hip, torch = gpu
+    n = 128                                     # whole 64 x 64 tiles: the fused y+z kernel runs
+    vol = torch.empty((n, n, n), device="cuda")
+    hip.synth_lattice(vol, 0, 5)
+    torch.cuda.synchronize()
+    det, kp, desc = api.Detector(), api.KeypointStore(), api.DescriptorStore()
+    assert det.detect_keypoints_device(vol.data_ptr(), n, n, n, kp) == 0
+    t = det.timings()
+    lt = det.launch_timings()
+    for b in range(6):                          # six blurs of octave 0, x pass and fused y+z pass each
+        assert 0.0 < lt[b][0] < 0.01 and 0.0 < lt[b][1] < 0.01, (b, lt[b])
+    assert lt[6] == (0.0, 0.0) and lt[7] == (0.0, 0.0)
+    assert t["yz_last"] == lt[5][1]
+    assert 0.0 < t["detect_dev"] <= t["detect_wall"] + 1e-4
+    assert t["gauss"] > 0 and t["extrema"] > 0 and t["orient"] > 0
+    want = [det.level(0, o, s) for o in range(3) for s in range(-1, 5)]
+    nk = len(kp)
+    assert nk > 50
+    # the pyramid alone, on a fresh detector and on the one that has just detected
+    for d2 in (api.Detector(), det):
+        assert d2.build_pyramid_device(vol.data_ptr(), n, n, n) == 0
+        got = [d2.level(0, o, s) for o in range(3) for s in range(-1, 5)]
+        for a, b in zip(want, got):
+            np.testing.assert_array_equal(a, b)
+        assert d2.timings()["gauss"] > 0 and d2.num_candidates() == 0
+    # ... and the detector still detects and describes afterwards
+    assert det.detect_keypoints_device(vol.data_ptr(), n, n, n, kp) == 0 and len(kp) == nk
+    assert det.extract_descriptors(kp, desc) == 0
+    clk = det.describe_clock()
+    assert clk is not None
+    cycles, seconds = clk
+    assert 0.5e9 < cycles / seconds < 3.5e9, (cycles, seconds)
+    assert 0.0 < seconds <= det.timings()["describe"] + 1e-4     # (the probe wave lives no longer than the stage)
+    assert api.Detector().describe_clock() is None          # nothing launched yet: says so, reads nothing
