@@ -2184,15 +2184,28 @@ __device__ __forceinline__ void orient_serial(const sift3d_hip_level *__restrict
         // The other lanes are masked off, and one pair of 16-byte reads serves both kinds of
         // row (4 voxels of a double row are 32 bytes, of a float row the first 16 of them): an
         // LDS read costs by the instruction and by the bytes it moves.
+        // (round 5: the reads of HALF a batch are issued back to back, then its 32 dependent adds run -- left to
+        // the compiler every group of four adds waited for its own pair of reads, an LDS round trip sixteen times
+        // per batch, and the longest window's batches are what k_orient_fix lasts)
         if (lane < 9) {
 #pragma unroll
-            for (int j = 0; j < 64; j += 4) {
-                const uint4 u0 = *reinterpret_cast<const uint4 *>(arow + (size_t)j * astride);
-                const uint4 u1 = *reinterpret_cast<const uint4 *>(arow + (size_t)j * astride + 16);
-                dacc += __hiloint2double((int)u0.y, (int)u0.x); facc += __uint_as_float(u0.x);
-                dacc += __hiloint2double((int)u0.w, (int)u0.z); facc += __uint_as_float(u0.y);
-                dacc += __hiloint2double((int)u1.y, (int)u1.x); facc += __uint_as_float(u0.z);
-                dacc += __hiloint2double((int)u1.w, (int)u1.z); facc += __uint_as_float(u0.w);
+            for (int h = 0; h < 64; h += 32) {
+                double2 u0[8], u1[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    u0[k] = *reinterpret_cast<const double2 *>(arow + (size_t)(h + 4 * k) * astride);
+                    u1[k] = *reinterpret_cast<const double2 *>(arow + (size_t)(h + 4 * k) * astride + 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    // (a float row's four voxels are the four dwords of u0)
+                    dacc += u0[k].x; facc += __int_as_float(__double2loint(u0[k].x));
+                    dacc += u0[k].y; facc += __int_as_float(__double2hiint(u0[k].x));
+                    dacc += u1[k].x; facc += __int_as_float(__double2loint(u0[k].y));
+                    dacc += u1[k].y; facc += __int_as_float(__double2hiint(u0[k].y));
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         wave_lds_sync();
