@@ -9,10 +9,10 @@ last $O/bench_register.json > $P/r05_bench_register.json
 last $O/kstats_bench.json > $P/r05_bench_step_profiled.json
 cp $O/kstats/run_kernel_stats.csv $P/r05_kernel_stats_step.csv
 cp $O/kstats/run_kernel_trace.csv $P/r05_kernel_trace_step.csv
-cp $O/pmc_fetch/*/*_counter_collection.csv $P/r05_pmc_fetch_size_fir512.csv
-cp $O/pmc_write/*/*_counter_collection.csv $P/r05_pmc_write_size_fir512.csv
-cp $O/pmc_pyr_fetch/*/*_counter_collection.csv $P/r05_pmc_fetch_size_pyramid512.csv
-cp $O/pmc_pyr_write/*/*_counter_collection.csv $P/r05_pmc_write_size_pyramid512.csv
+cp $(ls -t $O/pmc_fetch/*/*_counter_collection.csv | head -1) $P/r05_pmc_fetch_size_fir512.csv
+cp $(ls -t $O/pmc_write/*/*_counter_collection.csv | head -1) $P/r05_pmc_write_size_fir512.csv
+cp $(ls -t $O/pmc_pyr_fetch/*/*_counter_collection.csv | head -1) $P/r05_pmc_fetch_size_pyramid512.csv
+cp $(ls -t $O/pmc_pyr_write/*/*_counter_collection.csv | head -1) $P/r05_pmc_write_size_pyramid512.csv
 cp $O/pmc_desc/a/run_counter_collection.csv $P/r05_pmc_describe_a.csv
 cp $O/pmc_desc/b/run_counter_collection.csv $P/r05_pmc_describe_b.csv
 cp $O/traffic.json $P/traffic.json

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5: everything the committed profiles/r05_* come from, one call (the library is built before: rocprofv3 --pmc
 # initialises the GPU before Python starts)
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5final; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5final; rm -rf $O; mkdir -p $O
 cd $R
 echo "== bench"; timeout -k 10 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2>$O/bench.err; python3 - <<PY
 import json
