@@ -379,6 +379,8 @@ def main():
                     help="skip the strong_1024 sub-record (BASELINE configs[3]: one 1024^3 volume as N Z-slabs) "
                          "that every default run carries beside its main line")
     ap.add_argument("--no-host", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
+    ap.add_argument("--no-pyramid-leg", action="store_true",
+                    help="skip the pyramid-only leg (a kernel trace of the run then holds in-step launches only)")
     ap.add_argument("--rehearse-threads", type=int, default=0, metavar="R",
                     help="N=1 only: R slab drivers as R threads of this process on the one device "
                          "(sharded_c.StreamThreadTransport) -- exercises the N = R code path and geometry where "
@@ -676,15 +678,15 @@ def main():
     # pyramid-only leg: the Gaussian pyramid with the device to itself (inside the step its last launches
     # share the device with octave 0's extrema sweep, which starts as soon as octave 0 is complete)
     pyr_alone = None
-    if use_api:
+    if use_api and not a.no_pyramid_leg:
         ts = []
         for i in range(a.steps + 1):
             assert det.build_pyramid_device(vol.data_ptr(), n, n, nz_total) == 0
             if i:
                 ts.append(det.timings()["gauss_dev"])
         pyr_alone = pyramid_record(n, nz_total, float(np.median(ts)))
-    if use_api and not a.no_micro and not a.strong:
-        kb = kernel_microbench(torch, hip, n)
+    if use_api and not a.strong:
+        kb = kernel_microbench(torch, hip, n) if not a.no_micro else []
         alone = {k["kernel"]: k for k in kb if k["in_pipeline"]}
         # every octave-0 pyramid launch of the timed steps, HIP events around each on the stream it runs on
         # (sift3d_amd_timings [10..]): mean / median over the steps.  roofline.kernel = the LONGEST of them.

@@ -12,7 +12,7 @@ echo "== rehearsal 8 ranks (weak main line + strong_1024 sub-record)"; timeout -
 echo "== register"; timeout -k 10 400 python bench.py --register --steps 3 --warmup 1 > $O/bench_register.json 2>$O/reg.err; tail -c 400 $O/bench_register.json; echo
 cd /tmp && export TMPDIR=/tmp
 echo "== kernel stats (in-step launches only)"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/kstats -o run --output-format csv -- python3 $R/bench.py --no-cpu --no-host --no-micro --no-strong-leg --steps 10 --warmup 3 > $O/kstats_bench.json 2> $O/kstats.err
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/kstats -o run --output-format csv -- python3 $R/bench.py --no-cpu --no-host --no-micro --no-strong-leg --no-pyramid-leg --steps 10 --warmup 3 > $O/kstats_bench.json 2> $O/kstats.err
 tail -c 900 $O/kstats_bench.json; echo
 echo "== fir pmc"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/profiles/pmc_fir.py > $O/pmc_fetch.log 2>&1 &&
