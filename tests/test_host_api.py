@@ -302,3 +302,21 @@ def test_read_image_nifti_variants(api, tmp_path):
         api.Image.read(str(tmp_path / "missing.nii"))
     with pytest.raises(IOError):
         api.Image.read(str(tmp_path / "x.img"))
+
+
+def test_bench_contract_helpers():
+    """bench.py's algorithmic byte model is SURVEY.md 8(d)'s (24 B per voxel and blur; 6 blurs on octave 0, 5 on
+    every later one: 21.63 GB at 512^3, 2.70 GB at 256^3, 42.2 MB at 64^3), and the counts every run checks itself
+    against are the reference's (tests/golden/g5_512.npz) where the reference ran the workload."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert abs(b.pyramid_algorithmic_bytes(512, 512, 512) / 1e9 - 21.63) < 0.01
+    assert abs(b.pyramid_algorithmic_bytes(256, 256, 256) / 1e9 - 2.70) < 0.01
+    assert abs(b.pyramid_algorithmic_bytes(64, 64, 64) / 1e6 - 42.2) < 0.1
+    assert b.HBM_PEAK_GBS == 8000.0
+    assert b.expected_counts(False, 512, 1) == b.expected_counts(True, 512, 1)
+    assert b.expected_counts(True, 1024, 8) == (1249357, 332413) and b.expected_counts(False, 300, 1) is None
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g5_512.npz"))
+    assert b.expected_counts(False, 512, 1) == (int(g["ncand"]), int(g["nkp"]))
