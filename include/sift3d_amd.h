@@ -569,6 +569,18 @@ SIFT3D_AMD_API size_t sift3d_hip_describe_wlut_floats(int nlevels);
 SIFT3D_AMD_API int
 sift3d_hip_describe_wlut(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
                          uint32_t n, float *d_hist, float *d_wlut, void *stream);
+/* The full entry: as sift3d_hip_describe_ex with the scratch of the split windows.  The fast kernel sums a window
+ * in four parts (ranges of its planes: work items of a quarter of the size shorten the drain of the persistent
+ * kernel from ~1 ms to ~0.3 at 512^3) and the wave that finishes a keypoint's last part adds the parts' histograms
+ * in part order -- a function of the keypoint alone, so every entry of this family gives the same bits for the
+ * same keypoint.  d_part: device scratch of sift3d_hip_describe_part_bytes(n - n_exact) bytes (3.2 KB per part,
+ * 12.8 KB per keypoint) or NULL; the entries without the argument allocate it for the call and free it behind a
+ * stream synchronisation. */
+SIFT3D_AMD_API size_t sift3d_hip_describe_part_bytes(uint32_t n);
+SIFT3D_AMD_API int
+sift3d_hip_describe_parts(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
+                          uint32_t n, uint32_t n_exact, float *d_hist, float *d_hist2, float *d_wlut,
+                          void *d_part, void *stream);
 /* Clock probe of the last descriptor launch through d_wlut (the fast kernel; exact != 0: the reference-order
  * one): shader cycles and ticks of the constant 100 MHz counter during which the launch's first -- persistent --
  * wave was alive.  cycles / (ticks / 1e8) = the clock the device held under the kernel.  Blocks on `stream`. */

@@ -1,0 +1,3 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; cd $R
+timeout -k 10 300 python scratch/tail2.py 2>&1 | tail -4

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void k_desc_wlut(const sift3d_hip_level *__res
 }
 
 constexpr int DWAVES = 4;   // keypoints (waves) per workgroup; they share the read-only tables
+constexpr int DPARTS = 4;   // parts a window is summed in (fast variant; see k_describe)
 
 // EXACT: the reference's accumulation ORDER and term arithmetic, for windows so large that a bin receives
 // enough terms for any other order to drift past 1e-5 of the reference's own (float, sequential) sums --
@@ -188,7 +189,8 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
                                                  uint32_t n,
                                                  float *__restrict__ out, float *__restrict__ out2,
                                                  const float *__restrict__ wlut,
-                                                 uint32_t *__restrict__ work DESC_ABLATE_ARG)
+                                                 uint32_t *__restrict__ work, float *__restrict__ part,
+                                                 uint32_t *__restrict__ done DESC_ABLATE_ARG)
 {
     // per wave: 2 * 3200 + 2016 + 1024 B; per workgroup 39.4 KB -> four workgroups = 16 waves per CU
     __shared__ float hist_[DWAVES][2 * HIST_LDS];   // one private histogram per half-wave
@@ -228,18 +230,28 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     // workgroup the three faster waves idled until the slowest was done -- their slots and LDS are released
     // per WORKGROUP -- which left ~15 % of the wave slots empty.  Every wave leaves the loop when the
     // counter passes the end of the list.  (work == nullptr: one keypoint per wave, by position.)
+    // Round 5: a window is summed in DPARTS parts (ranges of its planes), each a work item of its own, and the
+    // wave that finishes a keypoint's LAST part adds the parts' histograms in part order.  When the work counter
+    // runs out every wave finishes the item it holds, so the device drains for as long as the last items take:
+    // with whole windows ~1 ms of the 27 (measured: the kernel's time is 26.0 ms per list + 1.06 ms that do not
+    // scale with the list; for lists of one level alone the fixed part is 0.8 x that level's window time).
+    // The split is a function of the keypoint alone (never of its place in the list or of timing), so the
+    // result is too.  The reference-order variant is not split: its sums have one order.
+    const bool split = !EXACT && part != nullptr;
     for (bool first_pass = true;; first_pass = false) {
-    uint32_t ki;
+    uint32_t item;
     if (work) {
         uint32_t t = 0;
         if (lane == 0)
             t = atomicAdd(work, 1u);
-        ki = first + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        item = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     } else {
         if (!first_pass)
             break;
-        ki = first + blockIdx.x * DWAVES + wv;
+        item = blockIdx.x * DWAVES + wv;
     }
+    const uint32_t ki = first + (split ? item / DPARTS : item);
+    const int pp = split ? (int)(item % DPARTS) : 0;
     if (ki >= n)
         break;
     for (int i = lane; i < 2 * HIST_LDS; i += 64)
@@ -652,8 +664,19 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     const float cube_x = half_w * (fabsf(R[0]) + fabsf(R[1]) + fabsf(R[2])) * 1.001f;
     const float cube_y = half_w * (fabsf(R[3]) + fabsf(R[4]) + fabsf(R[5])) * 1.001f;
     const float cube_z = half_w * (fabsf(R[6]) + fabsf(R[7]) + fabsf(R[8])) * 1.001f;
-    const int zs = max(B.zs, (int)floorf(K.cz - cube_z / L.uz - 1.0f));
-    const int ze = min(B.ze, (int)ceilf(K.cz + cube_z / L.uz + 1.0f));
+    int zs = max(B.zs, (int)floorf(K.cz - cube_z / L.uz - 1.0f));
+    int ze = min(B.ze, (int)ceilf(K.cz + cube_z / L.uz + 1.0f));
+    if (split) {
+        // part pp: planes [zs + cut(pp), zs + cut(pp + 1)) of the window's planes -- the cuts at 0.33 / 0.5 / 0.67
+        // of the range give the four parts of a sphere about the same number of voxels
+        const int np_ = max(ze - zs + 1, 0);
+        const int c1 = (33 * np_ + 50) / 100, c2 = (np_ + 1) / 2, c3 = (67 * np_ + 50) / 100;
+        static_assert(DPARTS == 4, "three cuts");
+        const int lo = pp == 0 ? 0 : pp == 1 ? c1 : pp == 2 ? c2 : c3;
+        const int hi = pp == 0 ? c1 : pp == 1 ? c2 : pp == 2 ? c3 : np_;
+        ze = zs + hi - 1;
+        zs = zs + lo;
+    }
 #if DESC_OPT & 4
     // The scan's window test in two tiers.  The bin coordinates of voxel (pxs + xx, pys + yy) of a plane
     // are affine in (xx, yy): vb_i = c_i + a_i * xx + b_i * yy, sq = (dx0 + ux * xx)^2 + (dy0 + uy * yy)^2
@@ -791,6 +814,36 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
     if (!EXACT) {
         for (int i = lane; i < HIST_USED; i += 64)
             hist[i] = hist[i] + hist[HIST_LDS + i];
+        wave_sync();
+    }
+    if (split) {
+        // this part's histogram to memory; the wave that completes the keypoint adds the parts in part order.
+        // The parts were written by waves of other compute units and XCDs (whose L2s are not coherent with this
+        // one): every access of the hand-over is an agent-scope atomic -- the stores write through, the loads
+        // read at the coherence point (`sc1` on each instruction) -- and the stores are complete (vmcnt(0))
+        // before the arrival counter is bumped.  NO agent-scope fence: on gfx950 that is a write-back
+        // (`buffer_wbl2`) / invalidation (`buffer_inv`) of the XCD's whole L2 -- 170 000 of them cost the kernel
+        // 4.5 ms at 512^3 (measured: 31.5 against 27.0 ms).
+        float *mine = part + ((size_t)(ki - first) * DPARTS + (size_t)pp) * HIST_USED;
+        for (int i = lane; i < HIST_USED; i += 64)
+            __hip_atomic_store(mine + i, hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t arrived = 0;
+        if (lane == 0)
+            arrived = __hip_atomic_fetch_add(done + (ki - first), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+        if (arrived != DPARTS - 1) {
+            wave_sync();              // (the histogram is cleared for the next item behind these reads)
+            continue;
+        }
+        const float *all = part + (size_t)(ki - first) * DPARTS * HIST_USED;
+        for (int i = lane; i < HIST_USED; i += 64) {
+            float v = __hip_atomic_load(all + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int q = 1; q < DPARTS; q++)
+                v = v + __hip_atomic_load(all + (size_t)q * HIST_USED + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hist[i] = v;
+        }
         wave_sync();
     }
     for (int pass = 0; pass < 2; pass++) {
@@ -1001,10 +1054,18 @@ static unsigned describe_grid(uint32_t count, bool counted)
     return need < cap ? need : cap;
 }
 
-// records [0, n_exact) take the reference-order kernel, [n_exact, n) the fast one
+// scratch of the split windows (k_describe, DPARTS): the parts' histograms, then one arrival counter per keypoint
+size_t sift3d_hip_describe_part_bytes(uint32_t n)
+{
+    return n ? (size_t)n * DPARTS * HIST_USED * sizeof(float) + (size_t)n * sizeof(uint32_t) : 0;
+}
+
+// records [0, n_exact) take the reference-order kernel, [n_exact, n) the fast one, its windows in DPARTS parts
+// through d_part (sift3d_hip_describe_part_bytes(n - n_exact) bytes; nullptr: a temporary allocation, freed
+// behind a stream synchronisation -- the entries that take no scratch)
 static int describe_launch(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp, uint32_t n,
                            uint32_t n_exact, float *d_hist, float *d_hist2, const float *d_wlut,
-                           void *stream)
+                           void *d_part, void *stream)
 {
     if (n_exact > n)
         n_exact = n;
@@ -1022,14 +1083,33 @@ static int describe_launch(const sift3d_hip_level *d_levels, int nlevels, const 
     if (n_exact) {
         hipLaunchKernelGGL(k_describe<true>, dim3(describe_grid(n_exact, work != nullptr)), dim3(64 * DWAVES), 0,
                            (hipStream_t)stream, d_levels, d_kp, 0u, n_exact, d_hist, d_hist2, d_wlut,
-                           work DESC_ABLATE_PASS);
+                           work, (float *)nullptr, (uint32_t *)nullptr DESC_ABLATE_PASS);
         LAUNCH_CHECK();
     }
     if (n > n_exact) {
-        hipLaunchKernelGGL(k_describe<false>, dim3(describe_grid(n - n_exact, work != nullptr)),
-                           dim3(64 * DWAVES), 0, (hipStream_t)stream, d_levels, d_kp, n_exact, n, d_hist,
-                           d_hist2, d_wlut, work ? work + 1 : nullptr DESC_ABLATE_PASS);
-        LAUNCH_CHECK();
+        const uint32_t nf = n - n_exact;
+        void *tmp = nullptr;
+        if (!d_part) {
+            HIPCHK(hipMalloc(&tmp, sift3d_hip_describe_part_bytes(nf)));
+            d_part = tmp;
+        }
+        float *parts = reinterpret_cast<float *>(d_part);
+        uint32_t *done = reinterpret_cast<uint32_t *>(parts + (size_t)nf * DPARTS * HIST_USED);
+        hipError_t e = hipMemsetAsync(done, 0, (size_t)nf * sizeof(uint32_t), (hipStream_t)stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_describe<false>, dim3(describe_grid(nf * DPARTS, work != nullptr)),
+                               dim3(64 * DWAVES), 0, (hipStream_t)stream, d_levels, d_kp, n_exact, n, d_hist,
+                               d_hist2, d_wlut, work ? work + 1 : nullptr, parts, done DESC_ABLATE_PASS);
+            e = hipGetLastError();
+        }
+        if (tmp) {
+            const hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+            (void)hipFree(tmp);
+            if (e == hipSuccess)
+                e = e2;
+        }
+        if (e != hipSuccess)
+            return fail("k_describe", e, __FILE__, __LINE__);
     }
 #undef DESC_ABLATE_PASS
     return SIFT3D_SUCCESS;
@@ -1040,20 +1120,29 @@ int sift3d_hip_describe(const sift3d_hip_level *d_levels, const sift3d_hip_kp *d
 {
     if (!n)
         return SIFT3D_SUCCESS;
-    return describe_launch(d_levels, 0, d_kp, n, 0, d_hist, nullptr, nullptr, stream);
+    return describe_launch(d_levels, 0, d_kp, n, 0, d_hist, nullptr, nullptr, nullptr, stream);
+}
+
+// (d_part: scratch of sift3d_hip_describe_part_bytes(n - n_exact) bytes, or NULL)
+int sift3d_hip_describe_parts(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
+                              uint32_t n, uint32_t n_exact, float *d_hist, float *d_hist2, float *d_wlut,
+                              void *d_part, void *stream)
+{
+    if (!n)
+        return SIFT3D_SUCCESS;
+    if (!d_wlut || nlevels < 1)
+        return describe_launch(d_levels, 0, d_kp, n, n_exact, d_hist, d_hist2, nullptr, d_part, stream);
+    hipLaunchKernelGGL(k_desc_wlut, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, d_levels, nlevels,
+                       d_wlut);
+    return describe_launch(d_levels, nlevels, d_kp, n, n_exact, d_hist, d_hist2, d_wlut, d_part, stream);
 }
 
 int sift3d_hip_describe_ex(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_kp *d_kp,
                            uint32_t n, uint32_t n_exact, float *d_hist, float *d_hist2, float *d_wlut,
                            void *stream)
 {
-    if (!n)
-        return SIFT3D_SUCCESS;
-    if (!d_wlut || nlevels < 1)
-        return describe_launch(d_levels, 0, d_kp, n, n_exact, d_hist, d_hist2, nullptr, stream);
-    hipLaunchKernelGGL(k_desc_wlut, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, d_levels, nlevels,
-                       d_wlut);
-    return describe_launch(d_levels, nlevels, d_kp, n, n_exact, d_hist, d_hist2, d_wlut, stream);
+    return sift3d_hip_describe_parts(d_levels, nlevels, d_kp, n, n_exact, d_hist, d_hist2, d_wlut, nullptr,
+                                     stream);
 }
 
 // shader cycles and 100 MHz ticks the first wave of the last descriptor launch (fast kernel; exact != 0: the

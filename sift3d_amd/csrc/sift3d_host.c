@@ -154,6 +154,8 @@ struct _sift3d_detector {
     void *d_work2;         /* extrema work areas of octaves >= 1 (kept between the two phases) */
     size_t work2_off[64], work2_bytes;
     float *d_wlut;         /* per-level window-weight tables of the descriptor kernel */
+    void *d_dpart;         /* ... and the scratch of its split windows (sift3d_hip_describe_parts) */
+    size_t dpart_bytes;
     void *d_otab;          /* window tables + per-candidate sums of the orientation kernels */
     size_t otab_bytes;
     sift3d_hip_kp *h_kp;    /* the describe kernel's input list (page-locked; read by the kernel in place) */
@@ -941,6 +943,9 @@ static void free_device_pyramid(sift3d_detector *d)
     d->work2_bytes = 0;
     sift3d_hip_free(d->d_wlut);
     d->d_wlut = NULL;
+    sift3d_hip_free(d->d_dpart);
+    d->d_dpart = NULL;
+    d->dpart_bytes = 0;
     sift3d_hip_free(d->d_otab);
     d->d_otab = NULL;
     d->otab_bytes = 0;
@@ -2234,10 +2239,19 @@ int sift3d_extract_descriptors(sift3d_detector *const d, const sift3d_keypoint_s
     {
         float *dev_view = (float *)sift3d_hip_host_device_ptr(desc->hist);
         const sift3d_hip_kp *kp_view = (const sift3d_hip_kp *)sift3d_hip_host_device_ptr(d->h_kp);
+        const size_t need = sift3d_hip_describe_part_bytes((uint32_t)(num - (int)n_exact));
+        if (need > d->dpart_bytes) {
+            sift3d_hip_free(d->d_dpart);
+            d->dpart_bytes = 0;
+            d->d_dpart = sift3d_hip_malloc(need + need / 8);
+            if (!d->d_dpart)
+                return SIFT3D_FAILURE;
+            d->dpart_bytes = need + need / 8;
+        }
         if (!dev_view || !kp_view ||
-            sift3d_hip_describe_ex(d->d_levels, d->num_octaves * d->ngl, kp_view, (uint32_t)num,
-                                   (uint32_t)n_exact, dev_view, desc->keep_device ? desc->d_hist : NULL,
-                                   d->d_wlut, d->stream))
+            sift3d_hip_describe_parts(d->d_levels, d->num_octaves * d->ngl, kp_view, (uint32_t)num,
+                                      (uint32_t)n_exact, dev_view, desc->keep_device ? desc->d_hist : NULL,
+                                      d->d_wlut, need ? d->d_dpart : NULL, d->stream))
             return SIFT3D_FAILURE;
     }
     sift3d_hip_event_record(d->ev[7], d->stream);

@@ -98,6 +98,8 @@ struct sift3d_amd_sharded {
     void *d_work;
     size_t work_bytes;
     float *d_wlut;
+    void *d_dpart;         /* scratch of the descriptor kernel's split windows */
+    size_t dpart_bytes;
     void *d_otab;          /* orientation window tables + candidate sums (sift3d_hip_orient_tab) */
     size_t otab_bytes;
     sift3d_hip_cand *d_cand;
@@ -205,7 +207,7 @@ void sift3d_amd_sharded_free(sift3d_amd_sharded *S)
     sift3d_hip_free(S->d_levels); sift3d_hip_free(S->d_work); sift3d_hip_free(S->d_work2);
     sift3d_hip_free(S->d_cand);
     sift3d_hip_free(S->d_R); sift3d_hip_free(S->d_keep); sift3d_hip_free(S->d_xchg);
-    sift3d_hip_free(S->d_wlut); sift3d_hip_free(S->d_otab);
+    sift3d_hip_free(S->d_wlut); sift3d_hip_free(S->d_otab); sift3d_hip_free(S->d_dpart);
     sift3d_hip_host_free(S->h_xchg); sift3d_hip_host_free(S->h_kp);
     sift3d_hip_free(S->d_cnt); sift3d_hip_free(S->d_tab); sift3d_hip_free(S->d_out); sift3d_hip_free(S->d_pack);
     sift3d_hip_free(S->d_gath);
@@ -1202,9 +1204,19 @@ int sift3d_amd_sharded_describe(sift3d_amd_sharded *S, const sift3d_keypoint_sto
         /* (the kernel reads a keypoint's record once, as its wave starts: from the page-locked list in place) */
         float *dev_view = (float *)sift3d_hip_host_device_ptr(desc->hist);
         const sift3d_hip_kp *kp_view = (const sift3d_hip_kp *)sift3d_hip_host_device_ptr(S->h_kp);
+        const size_t need = sift3d_hip_describe_part_bytes((uint32_t)n - (uint32_t)n_exact);
+        if (need > S->dpart_bytes) {
+            sift3d_hip_free(S->d_dpart);
+            S->dpart_bytes = 0;
+            S->d_dpart = sift3d_hip_malloc(need + need / 8);
+            if (!S->d_dpart)
+                return SIFT3D_FAILURE;
+            S->dpart_bytes = need + need / 8;
+        }
         if (!dev_view || !kp_view ||
-            sift3d_hip_describe_ex(S->d_levels, S->num_octaves * S->ngl, kp_view, (uint32_t)n,
-                                   (uint32_t)n_exact, dev_view, NULL, S->d_wlut, S->stream) ||
+            sift3d_hip_describe_parts(S->d_levels, S->num_octaves * S->ngl, kp_view, (uint32_t)n,
+                                      (uint32_t)n_exact, dev_view, NULL, S->d_wlut, need ? S->d_dpart : NULL,
+                                      S->stream) ||
             sift3d_hip_stream_sync(S->stream))
             return SIFT3D_FAILURE;
     }
