@@ -3,17 +3,8 @@
 # initialises the GPU before Python starts)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5final; rm -rf $O; mkdir -p $O
 cd $R
-echo "== bench"; timeout -k 10 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2>$O/bench.err; python3 - <<PY
-import json
-d=json.loads(open('$O/bench.json').read().strip().splitlines()[-1]); d.pop('details',None); print(json.dumps(d)[:3800])
-PY
-echo "== sharded N=1"; timeout -k 10 300 python bench.py --sharded --no-cpu --no-micro --no-host --steps 10 --warmup 3 > $O/bench_sharded1.json 2>/dev/null; tail -c 700 $O/bench_sharded1.json; echo
-echo "== rehearsal 8 ranks (weak main line + strong_1024 sub-record)"; timeout -k 10 900 python bench.py --rehearse-threads 8 --steps 2 --warmup 1 --no-cpu > $O/rehearse8.json 2>$O/rehearse8.err; tail -c 1500 $O/rehearse8.json; echo; tail -3 $O/rehearse8.err
-echo "== register"; timeout -k 10 400 python bench.py --register --steps 3 --warmup 1 > $O/bench_register.json 2>$O/reg.err; tail -c 400 $O/bench_register.json; echo
+# the counter passes first: the bench line then reads THIS build's traffic.json / describe_model.json
 cd /tmp && export TMPDIR=/tmp
-echo "== kernel stats (in-step launches only)"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/kstats -o run --output-format csv -- python3 $R/bench.py --no-cpu --no-host --no-micro --no-strong-leg --no-pyramid-leg --steps 10 --warmup 3 > $O/kstats_bench.json 2> $O/kstats.err
-tail -c 900 $O/kstats_bench.json; echo
 echo "== fir pmc"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/profiles/pmc_fir.py > $O/pmc_fetch.log 2>&1 &&
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/profiles/pmc_fir.py > $O/pmc_write.log 2>&1 &&
@@ -28,4 +19,16 @@ python3 profiles/describe_model.py --parse $O/pmc_desc 2523709698 > $O/describe_
 head -c 1200 $O/describe_model.json; echo; python3 -c "
 import json; t=json.load(open('$O/traffic.json'))
 for k,v in sorted(t.items()): print(k, v['hbm_bytes'], v['ratio'])"
-ls $O/kstats
+cp $O/traffic.json $O/describe_model.json $R/profiles/
+echo "== bench"; timeout -k 10 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2>$O/bench.err; python3 - <<PY
+import json
+d=json.loads(open('$O/bench.json').read().strip().splitlines()[-1]); d.pop('details',None); print(json.dumps(d)[:3800])
+PY
+echo "== sharded N=1"; timeout -k 10 300 python bench.py --sharded --no-cpu --no-micro --no-host --steps 10 --warmup 3 > $O/bench_sharded1.json 2>/dev/null; tail -c 700 $O/bench_sharded1.json; echo
+echo "== rehearsal 8 ranks (weak main line + strong_1024 sub-record)"; timeout -k 10 900 python bench.py --rehearse-threads 8 --steps 2 --warmup 1 --no-cpu > $O/rehearse8.json 2>$O/rehearse8.err; tail -c 1500 $O/rehearse8.json; echo; tail -3 $O/rehearse8.err
+echo "== register"; timeout -k 10 400 python bench.py --register --steps 3 --warmup 1 > $O/bench_register.json 2>$O/reg.err; tail -c 400 $O/bench_register.json; echo
+cd /tmp && export TMPDIR=/tmp
+echo "== kernel stats (in-step launches only)"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/kstats -o run --output-format csv -- python3 $R/bench.py --no-cpu --no-host --no-micro --no-strong-leg --no-pyramid-leg --steps 10 --warmup 3 > $O/kstats_bench.json 2> $O/kstats.err
+tail -c 900 $O/kstats_bench.json; echo
+cd $R; ls $O/kstats
