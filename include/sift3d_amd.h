@@ -98,7 +98,7 @@ sift3d_amd_image_info(const sift3d_image *im, int *dims4, double *units3);
  * the main stream when octave 0 is complete -- their sum can exceed [7]. */
 #define SIFT3D_AMD_TIMED_BLURS 8
 /* [10+2B] the device span of the whole detect call (first to last stage event): [7] minus this is what the host
- * adds (enqueueing, two synchronisations, the candidate -> keypoint compaction) */
+ * adds (enqueueing, two synchronisations, the candidate -> keypoint compaction); [10+2B+1] the compaction alone */
 #define SIFT3D_AMD_NUM_TIMINGS (10 + 2 * SIFT3D_AMD_TIMED_BLURS + 2)
 SIFT3D_AMD_API const double *
 sift3d_amd_timings(const sift3d_detector *det);

@@ -393,6 +393,7 @@ class Detector:
                  "detect_wall", "describe_wall", "yz_last")
         out = dict(zip(names, [p[i] for i in range(len(names))]))
         out["detect_dev"] = p[10 + 2 * TIMED_BLURS]       # first to last stage event of detect
+        out["compact_host"] = p[10 + 2 * TIMED_BLURS + 1]  # the host's candidate -> keypoint compaction
         return out
 
     def describe_clock(self):

@@ -1956,6 +1956,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     kp->nx = d->odims[0][0];
     kp->ny = d->odims[0][1];
     kp->nz = d->odims[0][2];
+    d->t[10 + 2 * SIFT3D_AMD_TIMED_BLURS + 1] = now_s();        /* (the compaction's seconds: below) */
     {
         const int nt = host_threads(count);
         size_t pre[HOST_THREADS_MAX + 1];
@@ -2017,6 +2018,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
 
     d->t_pending |= 1;                  /* (the stage events are read when sift3d_amd_timings asks) */
     d->t[7] = now_s() - t_start;
+    d->t[10 + 2 * SIFT3D_AMD_TIMED_BLURS + 1] = now_s() - d->t[10 + 2 * SIFT3D_AMD_TIMED_BLURS + 1];
     return SIFT3D_SUCCESS;
 }
 
