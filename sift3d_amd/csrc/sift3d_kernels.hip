@@ -1418,6 +1418,33 @@ struct ExSweep {
     unsigned *exact;          // k_extrema_sweep3g<.., true>: the five max|DoG| of the octave are gathered here
 };
 
+// v_max3_f32 / v_min3_f32 (operands that are not NaN: the result is the exact maximum / minimum)
+__device__ __forceinline__ float max3f(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min3f(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ float max2f(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float min2f(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v)
 {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);   // out-of-row lanes read 0
@@ -1538,7 +1565,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ float4 tile[2][3][TY + 2][TXQ];
     const int qx = threadIdx.x % TXQ, ty = threadIdx.x / TXQ;
     const int q16 = qx & 15;               // position in the 16-lane row = the 64-voxel mask word
-    const int x = (blockIdx.x * TXQ + qx) * 4, y0 = blockIdx.y * TY, y = y0 + ty;
+    // Workgroups go to the eight XCDs round robin in launch order, and an XCD's L2 is its own: tiles that share
+    // halo rows (y neighbours) should meet in ONE L2.  XCD k takes the k-th eighth of the tiles in (x, y, z
+    // segment) order -- at 512^3 exactly one z segment --, in that order.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, T = gx * gy * gridDim.z;
+        const unsigned L = bx + gx * (by + gy * bz), xcd = L & 7u, j = L >> 3;
+        const unsigned q = T >> 3, r = T & 7u;
+        const unsigned t = xcd * q + (xcd < r ? xcd : r) + j;
+        bx = (int)(t % gx);
+        by = (int)((t / gx) % gy);
+        bz = (int)(t / (gx * gy));
+    }
+    const int x = (bx * TXQ + qx) * 4, y0 = by * TY, y = y0 + ty;
     const int nx = S.nx, ny = S.ny;
     const size_t ys = nx, zs = (size_t)nx * ny;
     const bool col = x < nx && y < ny;                 // (nx % 4 == 0: whole quads)
@@ -1550,7 +1590,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int hr = threadIdx.x / TXQ;                  // 0: row above, 1: row below (halo threads)
     const int yh = hr == 0 ? max(y0 - 1, 0) : min(y0 + TY, ny - 1);
     const size_t oh = (size_t)yh * ys + xc;
-    const int p0 = S.z_lo + blockIdx.z * S.ts, p1 = min(p0 + S.ts, S.z_hi);
+    const int p0 = S.z_lo + bz * S.ts, p1 = min(p0 + S.ts, S.z_hi);
     if (p0 >= p1)
         return;
     float thr[3];
@@ -1566,7 +1606,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     };
     float mx[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
     auto amax4 = [](float mm, const float4 &v) {
-        return fmaxf(fmaxf(mm, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        float r;
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(mm), "v"(v.x), "v"(v.y));
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(r), "v"(v.z), "v"(v.w));
+        return r;
     };
     // differences 1..3 at planes z-1 (m), z (c), z+1 (p); Gaussian levels 1 and 4 at plane z
     float4 m[3], c[3], p[3], g1c, g4c;
@@ -1684,14 +1727,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int e = 0; e < 4; e++) {
                 const float v = cv[e];
                 const float xm = e > 0 ? cv[e - 1] : lf[i], xp = e < 3 ? cv[e + 1] : rt[i];
-                // (no short circuit: in a wave some lane nearly always passes the threshold, so
-                // branches only cost)
-                const bool hit =
-                    okx[e] & ((v > thr[i]) | (v < -thr[i])) &                          // sift.c:842
-                    (((v > pr[e]) & (v > xp) & (v > xm) & (v > dd[e]) & (v > uu[e]) & (v > zm[e]) &
-                      (v > zp[e]) & (v > ne[e])) |
-                     ((v < pr[e]) & (v < xp) & (v < xm) & (v < dd[e]) & (v < uu[e]) & (v < zm[e]) &
-                      (v < zp[e]) & (v < ne[e])));                                     // sift.c:844-849
+                // "greater than each of the eight" = greater than their maximum (sift.c:844-849; the differences
+                // of finite samples are never NaN): 3 x v_max3 + v_max and the same for the minimum instead of
+                // sixteen compares and as many scalar ANDs -- the sweep's arithmetic, not its loads, is what a
+                // plane costs beyond the copy rate.  (No short circuit: in a wave some lane nearly always passes
+                // the threshold, so branches only cost.)
+                const float hi8 = max2f(max3f(max3f(max3f(uu[e], dd[e], zm[e]), zp[e], pr[e]), ne[e], xm), xp);
+                const float lo8 = min2f(min3f(min3f(min3f(uu[e], dd[e], zm[e]), zp[e], pr[e]), ne[e], xm), xp);
+                const bool hit = okx[e] & (fabsf(v) > thr[i]) &                       // sift.c:842
+                                 ((v > hi8) | (v < lo8));
                 nib |= hit ? (1 << e) : 0;
             }
             // 64-bit word of the row: voxel 4*qx + e -> bit 4*qx + e; OR over the 16 lanes
@@ -1700,7 +1744,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             lo |= dpp_i<0x112>(lo); hi |= dpp_i<0x112>(hi);
             lo |= dpp_i<0x114>(lo); hi |= dpp_i<0x114>(hi);
             lo |= dpp_i<0x118>(lo); hi |= dpp_i<0x118>(hi);
-            const int wcol = blockIdx.x * (TXQ / 16) + (qx >> 4);     // 64-voxel word of the row
+            const int wcol = bx * (TXQ / 16) + (qx >> 4);     // 64-voxel word of the row
             if (q16 == 15 && wcol < S.wpr && y < ny) {
                 const size_t w = (size_t)i * S.nwords + ((size_t)z * ny + y) * S.wpr + wcol;
                 *reinterpret_cast<uint2 *>(S.masks32 + 2 * w) = make_uint2((unsigned)lo, (unsigned)hi);
@@ -3664,7 +3708,7 @@ static int extrema_gauss6_impl(const float *const *d_g, const float *d_absmax, c
     }
     if (n_out > 0 && phase != 2) {
         // tile width: a whole wave per row where the rows are long enough -- 1 KB row segments
-        // (measured at 512^3: 1.6 ms for the stage against 1.9 / 2.0 with 512 / 256-byte segments,
+        // (measured at 512^3, the sweep alone: 0.58 ms against 0.66 / 0.80 with 512 / 256-byte segments,
         // although the 4-row tiles re-read more halo rows)
         const int txq = nx >= 256 ? 64 : nx >= 128 ? 32 : 16, tyy = 256 / txq;
         const long bxy = (long)((nx + 4 * txq - 1) / (4 * txq)) * ((ny + tyy - 1) / tyy);
