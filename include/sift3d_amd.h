@@ -98,8 +98,10 @@ sift3d_amd_image_info(const sift3d_image *im, int *dims4, double *units3);
  * the main stream when octave 0 is complete -- their sum can exceed [7]. */
 #define SIFT3D_AMD_TIMED_BLURS 8
 /* [10+2B] the device span of the whole detect call (first to last stage event): [7] minus this is what the host
- * adds (enqueueing, two synchronisations, the candidate -> keypoint compaction); [10+2B+1] the compaction alone */
-#define SIFT3D_AMD_NUM_TIMINGS (10 + 2 * SIFT3D_AMD_TIMED_BLURS + 2)
+ * adds (enqueueing, its synchronisations, the candidate -> keypoint compaction); [10+2B+1] the compaction alone;
+ * [10+2B+2], [10+2B+3] first stage event -> end of the orientation kernels of octave 0's candidates / of the
+ * other octaves' (the default schedule orients octave 0 while the smaller octaves are still swept; 0 otherwise) */
+#define SIFT3D_AMD_NUM_TIMINGS (10 + 2 * SIFT3D_AMD_TIMED_BLURS + 4)
 SIFT3D_AMD_API const double *
 sift3d_amd_timings(const sift3d_detector *det);
 
@@ -500,6 +502,7 @@ typedef struct {
     void *d_work;
     size_t work_bytes;
 } sift3d_hip_extrema_oct;
+#define SIFT3D_HIP_EXTREMA_MAX_OCT 12   /* octaves one sift3d_hip_extrema_gauss6_finish call takes */
 SIFT3D_AMD_API int
 sift3d_hip_extrema_gauss6_finish(const sift3d_hip_extrema_oct *octs, int n_oct, double peak_thresh,
                                  sift3d_hip_cand *d_out, uint32_t cap, uint32_t *d_count, void *stream);
@@ -544,6 +547,15 @@ sift3d_hip_orient_tab(const sift3d_hip_level *d_levels, int nlevels, const sift3
                       uint32_t n, double corner_thresh, float *d_R, int32_t *d_keep, void *d_tab,
                       uint32_t max_cand, void *stream);
 /* (d_tab = NULL: the serial sums for every candidate, = sift3d_hip_orient) */
+/* A PART of the candidate list on its own: candidates first .. first + n - 1 (d_cand, d_R, d_keep are the
+ * arrays of the WHOLE list), all of levels lv_lo .. lv_hi - 1.  Two parts with disjoint level ranges and
+ * different slots (0 or 1: launch plan and undecided list of their own) may run at the same time on two
+ * streams over one d_tab: the detector starts octave 0's candidates while the smaller octaves' extrema are
+ * still being found.  Results: those of one call over the whole list. */
+SIFT3D_AMD_API int
+sift3d_hip_orient_tab_part(const sift3d_hip_level *d_levels, int nlevels, int lv_lo, int lv_hi,
+                           const sift3d_hip_cand *d_cand, uint32_t first, uint32_t n, double corner_thresh,
+                           float *d_R, int32_t *d_keep, void *d_tab, uint32_t max_cand, int slot, void *stream);
 
 typedef struct {
     float R[9];

@@ -20,7 +20,7 @@ SIFT3D_SUCCESS = 0
 SIFT3D_FAILURE = -1
 SIFT3D_DOUBLE, SIFT3D_FLOAT, SIFT3D_INT = 0, 1, 2
 TIMED_BLURS = 8
-NUM_TIMINGS = 10 + 2 * TIMED_BLURS + 2
+NUM_TIMINGS = 10 + 2 * TIMED_BLURS + 4
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
@@ -394,6 +394,9 @@ class Detector:
         out = dict(zip(names, [p[i] for i in range(len(names))]))
         out["detect_dev"] = p[10 + 2 * TIMED_BLURS]       # first to last stage event of detect
         out["compact_host"] = p[10 + 2 * TIMED_BLURS + 1]  # the host's candidate -> keypoint compaction
+        # first stage event -> end of the orientation of octave 0's candidates / of the other octaves' (0: one part)
+        out["orient_oct0_end"] = p[10 + 2 * TIMED_BLURS + 2]
+        out["orient_rest_end"] = p[10 + 2 * TIMED_BLURS + 3]
         return out
 
     def describe_clock(self):

@@ -119,7 +119,8 @@ struct _sift3d_detector {
     void *stream, *copy_stream;
     void *oct_stream;      /* octaves >= 1 of the pyramid, beside the last levels of octave 0 */
     void *side_stream;     /* ... and their levels that no later octave depends on */
-    void *ev_fork, *ev_join, *ev_join2;
+    void *ev_fork, *ev_join, *ev_join2, *ev_part;
+    int parts_timed;       /* the last detect oriented octave 0 on its own (ev_part, ev_join: the parts' ends) */
     void *ev_blur[SIFT3D_AMD_TIMED_BLURS][3]; /* octave 0, blur s: before its x pass, between x and the fused
                             * y+z launch, after it (on the stream they run on) */
     unsigned yz_timed;     /* bit s: blur s of octave 0 took the fused y+z kernel in the last detect */
@@ -1225,6 +1226,7 @@ void sift3d_free_detector(sift3d_detector *d)
     sift3d_hip_event_destroy(d->ev_fork);
     sift3d_hip_event_destroy(d->ev_join);
     sift3d_hip_event_destroy(d->ev_join2);
+    sift3d_hip_event_destroy(d->ev_part);
     for (i = 0; i < SIFT3D_AMD_TIMED_BLURS * 3; i++)
         sift3d_hip_event_destroy(d->ev_blur[i / 3][i % 3]);
     sift3d_hip_event_destroy(d->ev_pyr[0]);
@@ -1277,6 +1279,8 @@ const double *sift3d_amd_timings(const sift3d_detector *dc)
         }
         d->t[9] = last >= 0 ? d->t[10 + SIFT3D_AMD_TIMED_BLURS + last] : 0.0;
         d->t[10 + 2 * SIFT3D_AMD_TIMED_BLURS] = stage_seconds(d->ev[0], d->ev[5]);
+        d->t[10 + 2 * SIFT3D_AMD_TIMED_BLURS + 2] = d->parts_timed ? stage_seconds(d->ev[0], d->ev_part) : 0.0;
+        d->t[10 + 2 * SIFT3D_AMD_TIMED_BLURS + 3] = d->parts_timed ? stage_seconds(d->ev[0], d->ev_join) : 0.0;
     }
     if (d->t_pending & 2)
         d->t[5] = stage_seconds(d->ev[6], d->ev[7]);
@@ -1377,6 +1381,7 @@ static int ensure_device(sift3d_detector *d)
         !(d->oct_stream = sift3d_hip_stream_create_high()) ||
         !(d->side_stream = sift3d_hip_stream_create_high()) || !(d->ev_fork = sift3d_hip_event_create()) ||
         !(d->ev_join = sift3d_hip_event_create()) || !(d->ev_join2 = sift3d_hip_event_create()) ||
+        !(d->ev_part = sift3d_hip_event_create()) ||
         !(d->ev_pyr[0] = sift3d_hip_event_create()) || !(d->ev_pyr[1] = sift3d_hip_event_create()))
         return SIFT3D_FAILURE;
     for (i = 0; i < 32; i++)
@@ -1547,6 +1552,37 @@ static int host_threads(size_t n)
     return t;
 }
 
+/* scratch of the orientation kernels: sized by the level count and the candidate capacity */
+static int orient_scratch(sift3d_detector *d)
+{
+    const size_t need = sift3d_hip_orient_tab_bytes(d->num_octaves * d->ngl, d->cand_cap);
+    if (need > d->otab_bytes) {
+        sift3d_hip_free(d->d_otab);
+        d->otab_bytes = 0;
+        d->d_otab = sift3d_hip_malloc(need);
+        /* zeroed once: the tables carry a validity mark (they are kept between calls); complete before any
+         * stream's kernels use it */
+        if (!d->d_otab || sift3d_hip_memset(d->d_otab, 0, need, d->stream) || sift3d_hip_stream_sync(d->stream))
+            return SIFT3D_FAILURE;
+        d->otab_bytes = need;
+    }
+    return SIFT3D_SUCCESS;
+}
+
+/* Candidates first .. first + n - 1 (all of levels lv_lo .. lv_hi - 1) through the orientation kernels.  R and
+ * the keep flags are written by the kernels straight into the page-locked host arrays (mapped into the device's
+ * address space; only kept candidates' matrices are written): no device staging, no copy after the kernels. */
+static int orient_part(sift3d_detector *d, int lv_lo, int lv_hi, uint32_t first, uint32_t n, int slot, void *stream)
+{
+    float *r_view = (float *)sift3d_hip_host_device_ptr(d->h_R);
+    int32_t *k_view = (int32_t *)sift3d_hip_host_device_ptr(d->h_keep);
+    if (!r_view || !k_view)
+        return SIFT3D_FAILURE;
+    return sift3d_hip_orient_tab_part(d->d_levels, d->num_octaves * d->ngl, lv_lo, lv_hi, d->d_cand, first, n,
+                                      d->corner_thresh, r_view, k_view, d->orient_serial ? NULL : d->d_otab,
+                                      d->cand_cap, slot, stream);
+}
+
 static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int ny, int nz,
                             double ux, double uy, double uz, sift3d_keypoint_store *kp, int pyramid_only)
 {
@@ -1556,7 +1592,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     const double t_start = now_s();
     uint32_t count = 0;
     uint64_t rng;
-    int o, s, attempt, side, overlap = 0, im_stored = 0;
+    int o, s, attempt, side, overlap = 0, im_stored = 0, oriented = 0;
 
     /* set_im_SIFT3D, sift.c:629-659 */
     d->have_im = 1;
@@ -1594,6 +1630,7 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     const int sched = 0;
 #endif
     d->yz_timed = 0;
+    d->parts_timed = 0;
     d->pyr_chains = 0;
     /* Default configuration on every octave (and a second stream at hand): the stages after the pyramid run
      * octave 0 on the main stream and the short launches of octaves >= 1 beside it -- in the DoG stage and
@@ -1808,11 +1845,13 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
     if (ensure_cand_capacity(d, d->cand_cap ? d->cand_cap : (1u << 18)))
         return SIFT3D_FAILURE;
     for (attempt = 0; attempt < 2; attempt++) {
+        int split = 0;
         if (sift3d_hip_memset(d->d_scalars + 1, 0, sizeof(uint32_t), d->stream))
             return SIFT3D_FAILURE;
         if (side) {
             /* the sweeps side by side, then scan + emission in octave order */
             int phase;
+            split = overlap && attempt == 0 && d->num_octaves - 1 <= SIFT3D_HIP_EXTREMA_MAX_OCT;
             /* three chains: octave 0 | octaves 1, 2 | the small octaves, whose 4-40 us launches (four per
              * octave, each waiting for its predecessor) otherwise queue behind octave 1's sweep and end the
              * stage 0.1 ms after octave 0 has finished */
@@ -1836,6 +1875,60 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                         oc[o].work_bytes = o ? sift3d_hip_extrema_work_bytes(d->odims[o][0], d->odims[o][1],
                                                                              d->odims[o][2], 3)
                                              : d->work_bytes;
+                    }
+                    if (split) {
+                        /* Octave 0's candidates are the head of the list whatever the smaller octaves hold
+                         * (sift.c:835-868: octave order), and they are most of it: their scan + emission and
+                         * their ORIENTATION (1.5 ms at 512^3, device-filling) start as soon as octave 0's sweep
+                         * has ended, on the main stream; the chains of the smaller octaves -- latency-bound
+                         * launches that end later -- finish beside them, and their candidates are emitted
+                         * behind octave 0's and oriented on the octave stream.  Same list, same order. */
+                        uint32_t count_a = 0;
+                        if (sift3d_hip_extrema_gauss6_finish(oc, 1, d->peak_thresh, d->d_cand, d->cand_cap,
+                                                             (uint32_t *)(d->d_scalars + 1), d->stream) ||
+                            sift3d_hip_memcpy_d2h(&count_a, d->d_scalars + 1, sizeof(count_a), d->stream) ||
+                            sift3d_hip_stream_sync(d->stream))
+                            return SIFT3D_FAILURE;
+                        sift3d_hip_event_record(d->ev[4], d->stream);
+                        /* (a list that does not fit: the rest is still counted, then everything is grown
+                         * below for the second attempt) */
+                        if (count_a <= d->cand_cap && orient_scratch(d))
+                            return SIFT3D_FAILURE;
+                        if (count_a && count_a <= d->cand_cap &&
+                            orient_part(d, 0, d->ngl, 0, count_a, 0, d->stream))
+                            return SIFT3D_FAILURE;
+                        /* (on the main stream, ordinary priority: with the smaller octaves' launches behind
+                         * it in the dispatch order the two parts end together -- measured; at the chains'
+                         * priority this part ends 0.25 ms earlier and the other one 0.2 ms later) */
+                        sift3d_hip_event_record(d->ev_part, d->stream);
+                        /* (the records' copy: behind the small octaves' sweeps on the side stream, which has
+                         * nothing else to do from there on) */
+                        if (sift3d_hip_event_record(d->ev_join2, d->side_stream) ||
+                            (count_a && count_a <= d->cand_cap &&
+                             sift3d_hip_memcpy_d2h(d->h_cand, d->d_cand, sizeof(sift3d_hip_cand) * (size_t)count_a,
+                                                   d->side_stream)) ||
+                            sift3d_hip_stream_wait_event(d->oct_stream, d->ev_join2) ||
+                            sift3d_hip_extrema_gauss6_finish(oc + 1, d->num_octaves - 1, d->peak_thresh, d->d_cand,
+                                                             d->cand_cap, (uint32_t *)(d->d_scalars + 1),
+                                                             d->oct_stream) ||
+                            sift3d_hip_memcpy_d2h(&count, d->d_scalars + 1, sizeof(count), d->oct_stream) ||
+                            sift3d_hip_stream_sync(d->oct_stream))
+                            return SIFT3D_FAILURE;
+                        if (count > d->cand_cap)
+                            break;              /* (count_a <= count) */
+                        if (count > count_a &&
+                            (orient_part(d, d->ngl, d->num_octaves * d->ngl, count_a, count - count_a, 1,
+                                         d->oct_stream) ||
+                             sift3d_hip_memcpy_d2h(d->h_cand + count_a, d->d_cand + count_a,
+                                                   sizeof(sift3d_hip_cand) * (size_t)(count - count_a),
+                                                   d->oct_stream)))
+                            return SIFT3D_FAILURE;
+                        if (sift3d_hip_event_record(d->ev_join, d->oct_stream) ||
+                            sift3d_hip_stream_wait_event(d->stream, d->ev_join))
+                            return SIFT3D_FAILURE;
+                        oriented = 1;
+                        d->parts_timed = 1;
+                        break;
                     }
                     rc = sift3d_hip_extrema_gauss6_finish(oc, d->num_octaves, d->peak_thresh, d->d_cand,
                                                           d->cand_cap, (uint32_t *)(d->d_scalars + 1), d->stream);
@@ -1867,12 +1960,24 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                             (uint32_t *)(d->d_scalars + 1), wk, wb, xs, phase))
                         return SIFT3D_FAILURE;   /* (coverage was established by the dogmax calls) */
                 }
-                if (phase == 1 && (sift3d_hip_event_record(d->ev_join, d->oct_stream) ||
-                                   sift3d_hip_stream_wait_event(d->stream, d->ev_join) ||
-                                   sift3d_hip_event_record(d->ev_join2, d->side_stream) ||
-                                   sift3d_hip_stream_wait_event(d->stream, d->ev_join2)))
+                if (phase == 1 && !split &&
+                    (sift3d_hip_event_record(d->ev_join, d->oct_stream) ||
+                     sift3d_hip_stream_wait_event(d->stream, d->ev_join) ||
+                     sift3d_hip_event_record(d->ev_join2, d->side_stream) ||
+                     sift3d_hip_stream_wait_event(d->stream, d->ev_join2)))
                     return SIFT3D_FAILURE;
             }
+        }
+        if (split) {
+            /* (the counts were read where the two parts were emitted) */
+            if (oriented || attempt > 0)
+                break;
+            /* the list does not fit: nothing of this attempt is kept (its launches must have ended before the
+             * arrays they use are replaced) */
+            if (sift3d_hip_stream_sync(d->stream) || sift3d_hip_stream_sync(d->oct_stream) ||
+                sift3d_hip_stream_sync(d->side_stream) || ensure_cand_capacity(d, count + count / 4 + 1024))
+                return SIFT3D_FAILURE;
+            continue;
         }
         for (o = 0; o < d->num_octaves && !side; o++) {
             sift3d_hip_extrema_level lv[8];
@@ -1914,39 +2019,25 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
         if (ensure_cand_capacity(d, count + count / 4 + 1024))
             return SIFT3D_FAILURE;
     }
-    sift3d_hip_event_record(d->ev[4], d->stream);
+    if (!oriented)
+        sift3d_hip_event_record(d->ev[4], d->stream);
     d->ncand = (int)count;
     range_stop(rng);
     rng = range_start("sift3d: orientation");
 
-    /* assign_orientations, sift.c:1109-1167 */
-    if (count) {
-        /* scratch of the orientation kernels: sized by the level count and the candidate capacity */
-        const size_t need = sift3d_hip_orient_tab_bytes(d->num_octaves * d->ngl, d->cand_cap);
-        if (need > d->otab_bytes) {
-            sift3d_hip_free(d->d_otab);
-            d->otab_bytes = 0;
-            d->d_otab = sift3d_hip_malloc(need);
-            /* zeroed once: the tables carry a validity mark (they are kept between calls) */
-            if (!d->d_otab || sift3d_hip_memset(d->d_otab, 0, need, d->stream))
-                return SIFT3D_FAILURE;
-            d->otab_bytes = need;
-        }
+    /* assign_orientations, sift.c:1109-1167 (the default schedule has started it above, octave 0 first) */
+    if (count && !oriented) {
         /* The candidate records are final (the host has just read their count): their copy runs on the
-         * side stream beside the orientation kernels.  R and the keep flags are written by the kernels
-         * straight into the page-locked host arrays (mapped into the device's address space; only kept
-         * candidates' matrices are written): no device staging, no copy after the kernels. */
-        float *r_view = (float *)sift3d_hip_host_device_ptr(d->h_R);
-        int32_t *k_view = (int32_t *)sift3d_hip_host_device_ptr(d->h_keep);
-        if (!r_view || !k_view ||
+         * side stream beside the orientation kernels. */
+        if (orient_scratch(d) ||
             sift3d_hip_memcpy_d2h(d->h_cand, d->d_cand, sizeof(sift3d_hip_cand) * (size_t)count,
                                   d->oct_stream) ||
-            sift3d_hip_orient_tab(d->d_levels, d->num_octaves * d->ngl, d->d_cand, count, d->corner_thresh,
-                                  r_view, k_view, d->orient_serial ? NULL : d->d_otab, d->cand_cap, d->stream))
+            orient_part(d, 0, d->num_octaves * d->ngl, 0, count, 0, d->stream))
             return SIFT3D_FAILURE;
     }
     sift3d_hip_event_record(d->ev[5], d->stream);
-    if (sift3d_hip_stream_sync(d->stream) || (count && sift3d_hip_stream_sync(d->oct_stream)))
+    if (sift3d_hip_stream_sync(d->stream) || (count && sift3d_hip_stream_sync(d->oct_stream)) ||
+        (oriented && sift3d_hip_stream_sync(d->side_stream)))
         return SIFT3D_FAILURE;
     range_stop(rng);
 

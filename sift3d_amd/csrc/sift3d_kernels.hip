@@ -1939,7 +1939,7 @@ __global__ __launch_bounds__(1024) void k_extrema_scan(uint32_t *__restrict__ bl
 // launch per octave, fourteen dependent short launches at 512^3): the octaves' block-count arrays are scanned
 // one after the other by the one workgroup (the running total carries over: octave order), and the emission
 // grid covers every octave's blocks -- a workgroup finds its octave in a table of first-block numbers.
-constexpr int EX_MAX_OCT = 12;
+constexpr int EX_MAX_OCT = SIFT3D_HIP_EXTREMA_MAX_OCT;
 struct ExOct {
     const float *g[4];                    // Gaussian levels 1..4: keypoint DoG level i = g[i] - g[i + 1]
     const unsigned long long *masks;      // [3][nwords]
@@ -2481,11 +2481,11 @@ constexpr size_t ORI_TAB_HEAD = 128, ORI_TAB_STRIDE = ORI_TAB_HEAD + (size_t)ORI
 constexpr int ORI_CPW = 4;                       // candidates (waves) per workgroup of k_orient_sums
 constexpr int ORI_PLAN_MAX = 62;                 // levels with a launch plan (4 words each after the count)
 
-__global__ __launch_bounds__(256) void k_orient_table(const sift3d_hip_level *__restrict__ levels, int nlevels,
-                                                      unsigned char *__restrict__ tabs)
+__global__ __launch_bounds__(256) void k_orient_table(const sift3d_hip_level *__restrict__ levels, int lv_lo,
+                                                      int lv_hi, unsigned char *__restrict__ tabs)
 {
-    const int t = blockIdx.x;
-    if (t >= nlevels)
+    const int t = lv_lo + (int)blockIdx.x;
+    if (t >= lv_hi)
         return;
     const sift3d_hip_level L = levels[t];
     unsigned char *tab = tabs + (size_t)t * ORI_TAB_STRIDE;
@@ -2631,13 +2631,13 @@ __global__ __launch_bounds__(256) void k_orient_groups(const sift3d_hip_cand *__
         head[11] = i + 1;
 }
 
-__global__ __launch_bounds__(64) void k_orient_plan(unsigned char *__restrict__ tabs, int nlevels)
+__global__ __launch_bounds__(64) void k_orient_plan(unsigned char *__restrict__ tabs, int lv_lo, int lv_hi,
+                                                    uint32_t *__restrict__ plan)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0)
         return;
-    uint32_t *plan = reinterpret_cast<uint32_t *>(tabs + (size_t)nlevels * ORI_TAB_STRIDE);
     uint32_t P = 0, G = 0;
-    for (int t = nlevels - 1; t >= 0 && G < ORI_PLAN_MAX; t--) {
+    for (int t = lv_hi - 1; t >= lv_lo && G < ORI_PLAN_MAX; t--) {
         const uint32_t *head = reinterpret_cast<const uint32_t *>(tabs + (size_t)t * ORI_TAB_STRIDE);
         const uint32_t S = head[10], m = head[11] - head[10];
         if (!m)
@@ -2661,7 +2661,8 @@ constexpr int OWAVES = 1;
 constexpr int ORI_SUMS = 10;   // doubles per candidate: A00 A01 A02 A11 A12 A22, sum g w (x, y, z), voxels
 __global__ __launch_bounds__(64 * ORI_CPW) void k_orient_sums(const sift3d_hip_level *__restrict__ levels,
                                                     const sift3d_hip_cand *__restrict__ cand, uint32_t n,
-                                                    const unsigned char *__restrict__ tabs, int nlevels,
+                                                    const unsigned char *__restrict__ tabs,
+                                                    const uint32_t *__restrict__ plan,
                                                     double *__restrict__ sums
 #ifdef SIFT3D_AMD_DIAG
                                                     , int ablate
@@ -2671,7 +2672,6 @@ __global__ __launch_bounds__(64 * ORI_CPW) void k_orient_sums(const sift3d_hip_l
     // which candidate: see k_orient_plan (wave-uniform, scalar loads)
     uint32_t ci = 0xffffffffu;
     {
-        const uint32_t *plan = reinterpret_cast<const uint32_t *>(tabs + (size_t)nlevels * ORI_TAB_STRIDE);
         const uint32_t G = plan[0], b = blockIdx.x;
         const uint32_t wave = threadIdx.x >> 6;
         for (uint32_t g = 0; g < G; g++) {
@@ -3829,18 +3829,65 @@ int sift3d_hip_orient(const sift3d_hip_level *d_levels, const sift3d_hip_cand *d
     return SIFT3D_SUCCESS;
 }
 
-// tables + launch plan (rounded up to 256 bytes), then ORI_SUMS doubles per candidate
+// tables + two launch plans (rounded up to 256 bytes), then ORI_SUMS doubles per candidate
+constexpr size_t ORI_PLAN_BYTES = 4 * (1 + 4 * (size_t)ORI_PLAN_MAX);
 static size_t orient_tab_head_bytes(int nlevels)
 {
-    return (((size_t)nlevels * ORI_TAB_STRIDE + 4 * (1 + 4 * ORI_PLAN_MAX)) + 255) & ~(size_t)255;
+    return (((size_t)nlevels * ORI_TAB_STRIDE + 2 * ORI_PLAN_BYTES) + 255) & ~(size_t)255;
 }
 
-// ... then ORI_SUMS doubles per candidate, then the list of the undecided (count + indices)
+// ... then ORI_SUMS doubles per candidate, then two lists of the undecided (count + indices each)
 size_t sift3d_hip_orient_tab_bytes(int nlevels, uint32_t max_cand)
 {
     return nlevels > 0 ? orient_tab_head_bytes(nlevels) + sizeof(double) * ORI_SUMS * (size_t)max_cand +
-                             sizeof(uint32_t) * ((size_t)max_cand + 1)
+                             2 * sizeof(uint32_t) * ((size_t)max_cand + 1)
                        : 0;
+}
+
+int sift3d_hip_orient_tab_part(const sift3d_hip_level *d_levels, int nlevels, int lv_lo, int lv_hi,
+                               const sift3d_hip_cand *d_cand, uint32_t first, uint32_t n, double corner_thresh,
+                               float *d_R, int32_t *d_keep, void *d_tab, uint32_t max_cand, int slot, void *stream)
+{
+    if (!n)
+        return SIFT3D_SUCCESS;
+    if (lv_lo < 0 || lv_hi > nlevels || lv_lo >= lv_hi || slot < 0 || slot > 1) {
+        snprintf(g_err, sizeof(g_err), "sift3d_hip_orient_tab_part: invalid arguments");
+        fprintf(stderr, "sift3d_amd: %s\n", g_err);
+        return SIFT3D_FAILURE;
+    }
+    // everything below sees the part as a list of its own: candidate i of the part is candidate first + i
+    const sift3d_hip_cand *cand = d_cand + first;
+    float *R = d_R + (size_t)9 * first;
+    int32_t *keep = d_keep + first;
+    if (!d_tab || nlevels > ORI_PLAN_MAX || (uint64_t)first + n > max_cand)
+        return sift3d_hip_orient(d_levels, cand, n, corner_thresh, R, keep, stream);
+    // window tables of the part's levels, parallel sums with decisions by margin, then the undecided
+    // candidates with the serial sums
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char *tabs = (unsigned char *)d_tab;
+    uint32_t *plan = reinterpret_cast<uint32_t *>(tabs + (size_t)nlevels * ORI_TAB_STRIDE + (size_t)slot * ORI_PLAN_BYTES);
+    hipLaunchKernelGGL(k_orient_table, dim3(lv_hi - lv_lo), dim3(256), 0, st, d_levels, lv_lo, lv_hi, tabs);
+    hipLaunchKernelGGL(k_orient_groups, dim3((n + 255) / 256), dim3(256), 0, st, cand, n, tabs, nlevels);
+    hipLaunchKernelGGL(k_orient_plan, dim3(1), dim3(64), 0, st, tabs, lv_lo, lv_hi, plan);
+    // (every level's share of the grid is rounded up to a multiple of 8 workgroups)
+    double *d_sums = reinterpret_cast<double *>(tabs + orient_tab_head_bytes(nlevels)) + (size_t)ORI_SUMS * first;
+    uint32_t *d_und = reinterpret_cast<uint32_t *>(reinterpret_cast<double *>(tabs + orient_tab_head_bytes(nlevels)) +
+                                                   (size_t)ORI_SUMS * max_cand) +
+                      (size_t)slot * ((size_t)max_cand + 1);
+    HIPCHK(hipMemsetAsync(d_und, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_orient_sums, dim3((n + ORI_CPW - 1) / ORI_CPW + 16 * (uint32_t)(lv_hi - lv_lo)),
+                       dim3(64 * ORI_CPW), 0, st, d_levels, cand, n, (const unsigned char *)tabs,
+                       (const uint32_t *)plan, d_sums
+#ifdef SIFT3D_AMD_DIAG
+                       , getenv("SIFT3D_AMD_ORI_ABLATE") ? atoi(getenv("SIFT3D_AMD_ORI_ABLATE")) : 0
+#endif
+                       );
+    hipLaunchKernelGGL(k_orient_decide, dim3((n + 63) / 64), dim3(64), 0, st, cand, n, corner_thresh, R, keep,
+                       (const unsigned char *)tabs, d_sums, d_und);
+    hipLaunchKernelGGL(k_orient_fix, dim3(n < 8192u ? n : 8192u), dim3(64), 0, st, d_levels, cand, n, corner_thresh,
+                       R, keep, d_und);
+    LAUNCH_CHECK();
+    return SIFT3D_SUCCESS;
 }
 
 int sift3d_hip_orient_tab(const sift3d_hip_level *d_levels, int nlevels, const sift3d_hip_cand *d_cand,
@@ -3851,29 +3898,8 @@ int sift3d_hip_orient_tab(const sift3d_hip_level *d_levels, int nlevels, const s
         return SIFT3D_SUCCESS;
     if (!d_tab || nlevels < 1 || nlevels > ORI_PLAN_MAX || n > max_cand)
         return sift3d_hip_orient(d_levels, d_cand, n, corner_thresh, d_R, d_keep, stream);
-    // window tables of all levels, parallel sums with decisions by margin, then the undecided
-    // candidates with the serial sums
-    hipLaunchKernelGGL(k_orient_table, dim3(nlevels), dim3(256), 0, (hipStream_t)stream, d_levels, nlevels,
-                       (unsigned char *)d_tab);
-    hipLaunchKernelGGL(k_orient_groups, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_cand, n,
-                       (unsigned char *)d_tab, nlevels);
-    hipLaunchKernelGGL(k_orient_plan, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned char *)d_tab, nlevels);
-    // (every level's share of the grid is rounded up to a multiple of 8 workgroups)
-    double *d_sums = reinterpret_cast<double *>((unsigned char *)d_tab + orient_tab_head_bytes(nlevels));
-    uint32_t *d_und = reinterpret_cast<uint32_t *>(d_sums + (size_t)ORI_SUMS * max_cand);
-    HIPCHK(hipMemsetAsync(d_und, 0, sizeof(uint32_t), (hipStream_t)stream));
-    hipLaunchKernelGGL(k_orient_sums, dim3((n + ORI_CPW - 1) / ORI_CPW + 16 * (uint32_t)nlevels), dim3(64 * ORI_CPW), 0, (hipStream_t)stream, d_levels,
-                       d_cand, n, (const unsigned char *)d_tab, nlevels, d_sums
-#ifdef SIFT3D_AMD_DIAG
-                       , getenv("SIFT3D_AMD_ORI_ABLATE") ? atoi(getenv("SIFT3D_AMD_ORI_ABLATE")) : 0
-#endif
-                       );
-    hipLaunchKernelGGL(k_orient_decide, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_cand, n,
-                       corner_thresh, d_R, d_keep, (const unsigned char *)d_tab, d_sums, d_und);
-    hipLaunchKernelGGL(k_orient_fix, dim3(n < 8192u ? n : 8192u), dim3(64), 0, (hipStream_t)stream, d_levels,
-                       d_cand, n, corner_thresh, d_R, d_keep, d_und);
-    LAUNCH_CHECK();
-    return SIFT3D_SUCCESS;
+    return sift3d_hip_orient_tab_part(d_levels, nlevels, 0, nlevels, d_cand, 0, n, corner_thresh, d_R, d_keep, d_tab,
+                                      max_cand, 0, stream);
 }
 
 int sift3d_hip_synth_lattice(float *d_dst, int nx, int ny, int nz, int z_off, uint64_t seed,

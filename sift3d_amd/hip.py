@@ -87,6 +87,8 @@ def lib():
         "sift3d_hip_orient": (C.c_int, [vp, vp, C.c_uint32, C.c_double, vp, vp, vp]),
         "sift3d_hip_orient_tab_bytes": (C.c_size_t, [C.c_int, C.c_uint32]),
         "sift3d_hip_orient_tab": (C.c_int, [vp, C.c_int, vp, C.c_uint32, C.c_double, vp, vp, vp, C.c_uint32, vp]),
+        "sift3d_hip_orient_tab_part": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_uint32, C.c_uint32,
+                                                 C.c_double, vp, vp, vp, C.c_uint32, C.c_int, vp]),
         "sift3d_hip_describe": (C.c_int, [vp, vp, C.c_uint32, vp, vp]),
         "sift3d_hip_set_mesh": (C.c_int, [C.POINTER(C.c_float)]),
         "sift3d_hip_synth_lattice": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, vp]),
@@ -261,6 +263,32 @@ def orient(d_levels, cands, corner_thresh):
     _check(lib().sift3d_hip_orient(d_levels.data_ptr(), dc.data_ptr(), n, float(corner_thresh),
                                    R.data_ptr(), keep.data_ptr(), current_stream()),
            "sift3d_hip_orient")
+    return R.cpu().numpy(), keep.cpu().numpy()
+
+
+def orient_tab(d_levels, nlevels, cands, corner_thresh, parts=None):
+    """sift3d_hip_orient_tab over the whole list, or -- parts = [(lv_lo, lv_hi, first, n), (..)] -- the list
+    in two parts that run at the same time on two streams (sift3d_hip_orient_tab_part)."""
+    import torch
+    n = len(cands)
+    L = lib()
+    dc = torch.from_numpy(np.ascontiguousarray(cands).view(np.uint8)).cuda()
+    R = torch.zeros((n, 9), dtype=torch.float32, device="cuda")
+    keep = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    tab = torch.zeros(L.sift3d_hip_orient_tab_bytes(nlevels, n), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    if parts is None:
+        _check(L.sift3d_hip_orient_tab(d_levels.data_ptr(), nlevels, dc.data_ptr(), n, float(corner_thresh),
+                                       R.data_ptr(), keep.data_ptr(), tab.data_ptr(), n, current_stream()),
+               "sift3d_hip_orient_tab")
+    else:
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for slot, (lv_lo, lv_hi, first, m) in enumerate(parts):
+            _check(L.sift3d_hip_orient_tab_part(d_levels.data_ptr(), nlevels, lv_lo, lv_hi, dc.data_ptr(), first, m,
+                                                float(corner_thresh), R.data_ptr(), keep.data_ptr(),
+                                                tab.data_ptr(), n, slot, streams[slot].cuda_stream),
+                   "sift3d_hip_orient_tab_part")
+    torch.cuda.synchronize()
     return R.cpu().numpy(), keep.cpu().numpy()
 
 

@@ -643,6 +643,45 @@ def test_orientation_parallel_sums_equal_serial_sums(gpu, oracle_mod, case):
 
 
 @pytest.mark.gpu
+def test_orientation_in_two_parts_equals_one_call(gpu, oracle_mod):
+    """sift3d_hip_orient_tab_part: the detector orients octave 0's candidates while the smaller octaves' extrema
+    are still being found -- two parts of one list, disjoint level ranges, two streams, one scratch.  R and the
+    keep flags must be those of one call over the whole list, and of the serial sums (sift.c:926-1102)."""
+    api, hip, torch = gpu
+    rng = np.random.default_rng(11)
+    vols = [oracle_mod.synth_survey(72), oracle_mod.synth_lattice(48, seed=3)]
+    levels, sd = [], [2.0, 2.5, 3.2]
+    for o, v in enumerate(vols):
+        for s in range(3):
+            t = torch.from_numpy(np.ascontiguousarray(v) * np.float32(1.0 + 0.1 * s)).cuda()
+            levels.append(dict(data=t, off=0, nz_glob=t.shape[0], units=(2.0 ** o,) * 3, octave=o,
+                               sd=sd[s] * 2.0 ** o))
+    d_levels, tab = hip.level_table(levels)
+    cands = np.zeros(0, hip.CAND_DTYPE)
+    first = []
+    for tag, L in enumerate(levels):
+        nz, ny, nx = L["data"].shape
+        m = 150 if tag < 3 else 40
+        # (sorted voxel indices: the list order of the extrema stage; some windows clipped by the faces)
+        idx = np.sort(rng.choice(np.arange(nx * ny * nz, dtype=np.uint32), m, replace=False))
+        z, y, x = idx // (nx * ny), (idx // nx) % ny, idx % nx
+        ok = (x >= 1) & (x <= nx - 2) & (y >= 1) & (y <= ny - 2) & (z >= 1) & (z <= nz - 2)
+        c = np.zeros(int(ok.sum()), hip.CAND_DTYPE)
+        c["idx"], c["tag"], c["val"] = idx[ok], tag, 1.0
+        first.append(len(cands))
+        cands = np.concatenate([cands, c])
+    n, na = len(cands), first[3]
+    R1, k1 = hip.orient_tab(d_levels, len(levels), cands, 0.4)
+    R2, k2 = hip.orient_tab(d_levels, len(levels), cands, 0.4, parts=[(0, 3, 0, na), (3, 6, na, n - na)])
+    R0, k0 = hip.orient(d_levels, cands, 0.4)
+    assert set(np.unique(k1)) <= {0, 1} and 0 < int(k1.sum()) < n
+    np.testing.assert_array_equal(k1, k2)
+    np.testing.assert_array_equal(k1, k0)
+    np.testing.assert_array_equal(R1[k1 == 1], R2[k1 == 1])
+    np.testing.assert_array_equal(R1[k1 == 1], R0[k1 == 1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["lattice160", "noise96", "spike128", "aniso", "retry128", "odd256x93x95"])
 def test_dogmax_gathered_by_the_sweep_equals_its_own_pass(gpu, oracle_mod, case):
     """Octave 0's dogmax scan (sift.c:821-826) has no pass of its own by default: the extrema sweep is
