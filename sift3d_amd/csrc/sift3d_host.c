@@ -1419,7 +1419,9 @@ static int ensure_cand_capacity(sift3d_detector *d, uint32_t cap)
     d->d_cand = (sift3d_hip_cand *)sift3d_hip_malloc(sizeof(sift3d_hip_cand) * (size_t)cap);
     d->h_cand = (sift3d_hip_cand *)sift3d_hip_host_alloc(sizeof(sift3d_hip_cand) * (size_t)cap);
     d->h_R = (float *)sift3d_hip_host_alloc(sizeof(float) * 9 * (size_t)cap);
-    d->h_keep = (int32_t *)sift3d_hip_host_alloc(sizeof(int32_t) * (size_t)cap);
+    /* (+ 4 page-locked words behind the flags: the candidate counts land there -- a copy into pageable memory
+     * would hold the host until it has been carried out) */
+    d->h_keep = (int32_t *)sift3d_hip_host_alloc(sizeof(int32_t) * ((size_t)cap + 4));
     if (!d->d_cand || !d->h_cand || !d->h_R || !d->h_keep)
         return SIFT3D_FAILURE;
     d->cand_cap = cap;
@@ -1884,11 +1886,26 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                          * launches that end later -- finish beside them, and their candidates are emitted
                          * behind octave 0's and oriented on the octave stream.  Same list, same order. */
                         uint32_t count_a = 0;
+                        volatile uint32_t *h_cnt = (volatile uint32_t *)(d->h_keep + d->cand_cap);
+                        /* both emissions are enqueued before the host waits for the first count: the smaller
+                         * octaves' scan starts from octave 0's total (ev_part orders the two on the device) and
+                         * runs when their sweeps have ended -- not when the host has come back from its wait
+                         * and has launched octave 0's orientation kernels, which it would then queue behind */
                         if (sift3d_hip_extrema_gauss6_finish(oc, 1, d->peak_thresh, d->d_cand, d->cand_cap,
                                                              (uint32_t *)(d->d_scalars + 1), d->stream) ||
-                            sift3d_hip_memcpy_d2h(&count_a, d->d_scalars + 1, sizeof(count_a), d->stream) ||
+                            sift3d_hip_memcpy_d2h((void *)(h_cnt + 0), d->d_scalars + 1, sizeof(uint32_t), d->stream) ||
+                            sift3d_hip_event_record(d->ev_part, d->stream) ||
+                            sift3d_hip_event_record(d->ev_join2, d->side_stream) ||
+                            sift3d_hip_stream_wait_event(d->oct_stream, d->ev_join2) ||
+                            sift3d_hip_stream_wait_event(d->oct_stream, d->ev_part) ||
+                            sift3d_hip_extrema_gauss6_finish(oc + 1, d->num_octaves - 1, d->peak_thresh, d->d_cand,
+                                                             d->cand_cap, (uint32_t *)(d->d_scalars + 1),
+                                                             d->oct_stream) ||
+                            sift3d_hip_memcpy_d2h((void *)(h_cnt + 1), d->d_scalars + 1, sizeof(uint32_t),
+                                                  d->oct_stream) ||
                             sift3d_hip_stream_sync(d->stream))
                             return SIFT3D_FAILURE;
+                        count = count_a = h_cnt[0];
                         sift3d_hip_event_record(d->ev[4], d->stream);
                         /* (a list that does not fit: the rest is still counted, then everything is grown
                          * below for the second attempt) */
@@ -1901,19 +1918,13 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                          * it in the dispatch order the two parts end together -- measured; at the chains'
                          * priority this part ends 0.25 ms earlier and the other one 0.2 ms later) */
                         sift3d_hip_event_record(d->ev_part, d->stream);
-                        /* (the records' copy: behind the small octaves' sweeps on the side stream, which has
-                         * nothing else to do from there on) */
-                        if (sift3d_hip_event_record(d->ev_join2, d->side_stream) ||
-                            (count_a && count_a <= d->cand_cap &&
+                        /* (the records' copy: on the side stream, which has nothing else to do from here on) */
+                        if ((count_a && count_a <= d->cand_cap &&
                              sift3d_hip_memcpy_d2h(d->h_cand, d->d_cand, sizeof(sift3d_hip_cand) * (size_t)count_a,
                                                    d->side_stream)) ||
-                            sift3d_hip_stream_wait_event(d->oct_stream, d->ev_join2) ||
-                            sift3d_hip_extrema_gauss6_finish(oc + 1, d->num_octaves - 1, d->peak_thresh, d->d_cand,
-                                                             d->cand_cap, (uint32_t *)(d->d_scalars + 1),
-                                                             d->oct_stream) ||
-                            sift3d_hip_memcpy_d2h(&count, d->d_scalars + 1, sizeof(count), d->oct_stream) ||
                             sift3d_hip_stream_sync(d->oct_stream))
                             return SIFT3D_FAILURE;
+                        count = h_cnt[1];
                         if (count > d->cand_cap)
                             break;              /* (count_a <= count) */
                         if (count > count_a &&
