@@ -15,6 +15,7 @@ cp $(ls -t $O/pmc_pyr_fetch/*/*_counter_collection.csv | head -1) $P/r05_pmc_fet
 cp $(ls -t $O/pmc_pyr_write/*/*_counter_collection.csv | head -1) $P/r05_pmc_write_size_pyramid512.csv
 cp $O/pmc_desc/a/run_counter_collection.csv $P/r05_pmc_describe_a.csv
 cp $O/pmc_desc/b/run_counter_collection.csv $P/r05_pmc_describe_b.csv
+cp $O/sweep_alone.txt $P/r05_sweep_alone.txt
 cp $O/traffic.json $P/traffic.json
 cp $O/describe_model.json $P/describe_model.json
 ls -la $P/r05_* $P/traffic.json $P/describe_model.json

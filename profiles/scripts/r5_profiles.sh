@@ -31,4 +31,14 @@ cd /tmp && export TMPDIR=/tmp
 echo "== kernel stats (in-step launches only)"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/kstats -o run --output-format csv -- python3 $R/bench.py --no-cpu --no-host --no-micro --no-strong-leg --no-pyramid-leg --steps 10 --warmup 3 > $O/kstats_bench.json 2> $O/kstats.err
 tail -c 900 $O/kstats_bench.json; echo
+echo "== the octave-0 extrema sweep alone"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/sweep -o run --output-format csv -- python3 $R/profiles/microbench/sweep_alone.py > $O/sweep.log 2>&1
+python3 - <<PY > $O/sweep_alone.txt
+import csv
+print(open("$O/sweep.log").read().strip().splitlines()[-1])
+for r in csv.DictReader(open("$O/sweep/run_kernel_stats.csv")):
+    if "extrema" in r["Name"] or "dogmax" in r["Name"] or "zero_mask" in r["Name"]:
+        print("%-64s calls %3s  avg %9.1f us  min %9.1f  max %9.1f" % (r["Name"][:64], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+PY
+cat $O/sweep_alone.txt
 cd $R; ls $O/kstats
