@@ -449,6 +449,48 @@ def test_detect_describe_vs_oracle(gpu, oracle_mod, n, gen):
     assert util.rel_err(desc.to_mat_rm(), o.desc_mat()) <= RTOL
 
 
+@pytest.mark.parametrize("case", ["coarse_only", "fine_only", "nothing"])
+def test_detect_when_a_part_of_the_list_is_empty_vs_oracle(gpu, oracle_mod, case):
+    """The detector emits and orients octave 0's candidates while the smaller octaves are still swept, then the
+    others' behind them (sift.c:835-868: octave order).  Either part may be empty: a volume whose only structure
+    is coarse (no extremum in octave 0), one whose candidates all lie in octave 0, a flat one."""
+    api, hip, torch = gpu
+    n = 96
+    z, y, x = np.meshgrid(*(np.arange(n, dtype=np.float32),) * 3, indexing="ij")
+    rng = np.random.default_rng(17)
+    vol = np.zeros((n, n, n), np.float32)
+    if case == "coarse_only":
+        for c in rng.uniform(20, n - 20, size=(6, 3)):
+            vol += np.exp(-((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) / (2 * 7.0 ** 2)).astype(np.float32)
+        kw = dict(peak_thresh=0.05)
+    elif case == "fine_only":
+        # (two octaves, 16^3 and 8^3; every candidate of this noise lies in the first)
+        vol = np.random.default_rng(1).random((16, 16, 16), dtype=np.float32)
+        kw = dict(peak_thresh=0.3)
+    else:
+        vol += 1.0
+        kw = {}
+    det, kp = api.Detector(**kw), api.KeypointStore()
+    assert det.detect_keypoints(api.Image.from_array(vol), kp) == 0
+    o = oracle_mod.Oracle(**kw)
+    assert o.detect(vol) == 0
+    cand = o.candidates()
+    assert det.num_candidates() == len(cand)
+    k, ok = kp.records(), o.keypoints()
+    assert len(k) == len(ok)
+    for f in ("o", "s", "xd", "yd", "zd", "sd", "strength"):
+        np.testing.assert_array_equal(k[f], ok[f], err_msg=f)
+    if len(k):
+        assert util.rel_err(k["R"], ok["R"]) <= RTOL
+    octs = set(int(v) for v in cand["o"])
+    if case == "coarse_only":
+        assert len(ok) > 0 and 0 not in octs
+    elif case == "fine_only":
+        assert len(ok) > 0 and octs == {0} and o.num_octaves == 2
+    else:
+        assert len(cand) == 0 and len(ok) == 0
+
+
 def test_g5_256_golden(gpu, oracle_mod):
     """BASELINE configs[1] (256^3, detect+describe, 1x MI355X) against the reference."""
     if not util.have("g5_256"):
