@@ -861,6 +861,9 @@ def test_pyramid_only_entry_and_launch_timings(gpu, oracle_mod):
     assert t["yz_last"] == lt[5][1]
     assert 0.0 < t["detect_dev"] <= t["detect_wall"] + 1e-4
     assert t["gauss"] > 0 and t["extrema"] > 0 and t["orient"] > 0
+    # the default schedule orients octave 0's candidates on their own: both parts end inside the device span
+    assert 0.0 < t["orient_oct0_end"] <= t["detect_dev"] + 1e-6
+    assert 0.0 < t["orient_rest_end"] <= t["detect_dev"] + 1e-6
     want = [det.level(0, o, s) for o in range(3) for s in range(-1, 5)]
     nk = len(kp)
     assert nk > 50
