@@ -1880,11 +1880,13 @@ static int detect_on_device(sift3d_detector *d, const float *d_vol, int nx, int 
                     }
                     if (split) {
                         /* Octave 0's candidates are the head of the list whatever the smaller octaves hold
-                         * (sift.c:835-868: octave order), and they are most of it: their scan + emission and
-                         * their ORIENTATION (1.5 ms at 512^3, device-filling) start as soon as octave 0's sweep
-                         * has ended, on the main stream; the chains of the smaller octaves -- latency-bound
-                         * launches that end later -- finish beside them, and their candidates are emitted
-                         * behind octave 0's and oriented on the octave stream.  Same list, same order. */
+                         * (sift.c:835-868: octave order) -- a third of it on the bench volume, whose blobs
+                         * put most extrema into octaves >= 1; more where the structure is fine.  Their scan +
+                         * emission and their ORIENTATION (device-filling: 1.5 ms for the whole list at 512^3)
+                         * start as soon as octave 0's sweep has ended, on the main stream; the chains of the
+                         * smaller octaves -- latency-bound launches that end later -- finish beside them, and
+                         * their candidates are emitted behind octave 0's and oriented on the octave stream,
+                         * whose kernels are dispatched first.  Same list, same order. */
                         uint32_t count_a = 0;
                         volatile uint32_t *h_cnt = (volatile uint32_t *)(d->h_keep + d->cand_cap);
                         /* both emissions are enqueued before the host waits for the first count: the smaller

@@ -2605,7 +2605,7 @@ __global__ __launch_bounds__(256) void k_orient_table(const sift3d_hip_level *__
     }
 }
 
-// Launch plan of k_orient_fast.  The candidates arrive sorted by (level, z, y, x).  Workgroups go
+// Launch plan of k_orient_sums.  The candidates arrive sorted by (level, z, y, x).  Workgroups go
 // to the eight XCDs in rotation (workgroup b runs on XCD b % 8), and every XCD has its own L2: if
 // consecutive candidates went to consecutive workgroups, all eight XCDs would walk the whole
 // volume and each would fetch it into its own L2 (measured: 13 GB of L2 fills for 1.8 GB of
