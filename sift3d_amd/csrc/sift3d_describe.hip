@@ -697,70 +697,77 @@ __global__ __launch_bounds__(64 * DWAVES) void k_describe(const sift3d_hip_level
         const int pxs = max(B.xs, (int)floorf(K.cx - xr)), pxe = min(B.xe, (int)ceilf(K.cx + xr));
         const int pys = max(B.ys, (int)floorf(K.cy - yr)), pye = min(B.ye, (int)ceilf(K.cy + yr));
         const int pbx = pxe - pxs + 1, pby = pye - pys + 1;
-        const int ppl = pbx > 0 && pby > 0 ? pbx * pby : 0;
         const int ox = pxs - B.xs, oy = pys - B.ys;
 #if DESC_OPT & 4
         const float dx0 = ((float)pxs - K.cx) * L.ux, dy0 = ((float)pys - K.cy) * L.uy, dz2 = dzp * dzp;
         const float wc0 = (R[0] * dx0 + R[3] * dy0 + R[6] * dzp + half_w) * bin_f;
         const float wc1 = (R[1] * dx0 + R[4] * dy0 + R[7] * dzp + half_w) * bin_f;
         const float wc2 = (R[2] * dx0 + R[5] * dy0 + R[8] * dzp + half_w) * bin_f;
-        // acc: passes by margin; the return value: neither passes nor fails by margin
-        auto cheap = [&](int xx_, int yy_, bool &acc) -> bool {
-            const float fx_ = (float)xx_, fy_ = (float)yy_;
-            const float v0 = __builtin_fmaf(wa0, fx_, __builtin_fmaf(wb0, fy_, wc0));
-            const float v1 = __builtin_fmaf(wa1, fx_, __builtin_fmaf(wb1, fy_, wc1));
-            const float v2 = __builtin_fmaf(wa2, fx_, __builtin_fmaf(wb2, fy_, wc2));
-            const float ex = __builtin_fmaf(fx_, L.ux, dx0), ey = __builtin_fmaf(fy_, L.uy, dy0);
-            const float sq_ = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, dz2));
+        // acc: passes by margin; the return value: neither passes nor fails by margin.  Two x-adjacent voxels of a
+        // row per call: what depends on the row alone (5 of a voxel's 14 fused multiply-adds) is formed once
+        auto cheap2 = [&](int xx_, int yy_, bool &acc0, bool &acc1) -> bool {
+            const float fx_ = (float)xx_, fy_ = (float)yy_, gx_ = (float)(xx_ + 1);
+            const float t0 = __builtin_fmaf(wb0, fy_, wc0), t1 = __builtin_fmaf(wb1, fy_, wc1),
+                        t2 = __builtin_fmaf(wb2, fy_, wc2);
+            const float ey = __builtin_fmaf(fy_, L.uy, dy0), sy = __builtin_fmaf(ey, ey, dz2);
+            const float v0 = __builtin_fmaf(wa0, fx_, t0), v1 = __builtin_fmaf(wa1, fx_, t1),
+                        v2 = __builtin_fmaf(wa2, fx_, t2);
+            const float u0 = __builtin_fmaf(wa0, gx_, t0), u1 = __builtin_fmaf(wa1, gx_, t1),
+                        u2 = __builtin_fmaf(wa2, gx_, t2);
+            const float ex = __builtin_fmaf(fx_, L.ux, dx0), fx2 = __builtin_fmaf(gx_, L.ux, dx0);
+            const float sq_ = __builtin_fmaf(ex, ex, sy), sq2 = __builtin_fmaf(fx2, fx2, sy);
             const float lo = fminf(fminf(v0, v1), v2), hi = fmaxf(fmaxf(v0, v1), v2);
-            acc = sq_ <= rad2_in && lo >= 1e-4f && hi <= 3.9999f;
-            const bool rej = sq_ > rad2_out || lo < -1e-4f || hi >= 4.0001f;
-            return !acc && !rej;
+            const float lo2 = fminf(fminf(u0, u1), u2), hi2 = fmaxf(fmaxf(u0, u1), u2);
+            acc0 = sq_ <= rad2_in && lo >= 1e-4f && hi <= 3.9999f;
+            acc1 = sq2 <= rad2_in && lo2 >= 1e-4f && hi2 <= 3.9999f;
+            const bool rej0 = sq_ > rad2_out || lo < -1e-4f || hi >= 4.0001f;
+            const bool rej1 = sq2 > rad2_out || lo2 < -1e-4f || hi2 >= 4.0001f;
+            return (!acc0 && !rej0) || (!acc1 && !rej1);
         };
 #endif
-        // (yy, xx) of this lane's voxel in the rectangle; a chunk of 64 voxels further it is
-        // (yy + q64, xx + r64), one more row if xx wraps.  Two chunks are tested per iteration
-        // (independent arithmetic: the second hides the latency of the first).
-        const int q64 = pbx > 0 ? 64 / pbx : 0, r64 = pbx > 0 ? 64 - q64 * pbx : 0;
-        int yy = pbx > 0 ? lane / pbx : 0, xx = pbx > 0 ? lane - yy * pbx : 0;
-        for (int c0 = 0; c0 < ppl; c0 += 128) {
-            int xx1 = xx + r64, yy1 = yy + q64;
-            if (xx1 >= pbx) {
-                xx1 -= pbx;
-                yy1++;
-            }
+        // A lane tests the voxels at positions 2 * lane and 2 * lane + 1 of a run of 128 positions of the rectangle
+        // (row-major = the reference's scan order inside a plane): two neighbours in x, of ONE row -- the
+        // rectangle is walked with an even width pbe >= pbx (the odd column, if any, is beyond the rectangle and
+        // never accepted).  128 positions further the pair is at (yy + q128, xx + r128), one more row if xx wraps
+        // (r128 and xx stay even).
+        const int pbe = pbx + (pbx & 1);
+        const int ppe = pbx > 0 && pby > 0 ? pbe * pby : 0;
+        const int q128 = pbe > 0 ? 128 / pbe : 0, r128 = pbe > 0 ? 128 - q128 * pbe : 0;
+        int yy = pbe > 0 ? (2 * lane) / pbe : 0, xx = pbe > 0 ? 2 * lane - yy * pbe : 0;
+        for (int c0 = 0; c0 < ppe; c0 += 128) {
 #if DESC_OPT & 4
             bool in0, in1;
-            const bool d0 = cheap(xx, yy, in0), d1 = cheap(xx1, yy1, in1);
-            if (__builtin_expect(__ballot(d0 || d1) != 0ull, 0)) {
+            if (__builtin_expect(__ballot(cheap2(xx, yy, in0, in1)) != 0ull, 0)) {
                 float sq, vbx, vby, vbz;
                 in0 = window(pxs + xx, pys + yy, z, sq, vbx, vby, vbz);
-                in1 = window(pxs + xx1, pys + yy1, z, sq, vbx, vby, vbz);
+                in1 = window(pxs + xx + 1, pys + yy, z, sq, vbx, vby, vbz);
             }
-            in0 = in0 && c0 + lane < ppl;
-            in1 = in1 && c0 + 64 + lane < ppl;
 #else
             float sq, vbx, vby, vbz;
-            const bool in0 = window(pxs + xx, pys + yy, z, sq, vbx, vby, vbz) && c0 + lane < ppl;
-            const bool in1 = window(pxs + xx1, pys + yy1, z, sq, vbx, vby, vbz) && c0 + 64 + lane < ppl;
+            bool in0 = window(pxs + xx, pys + yy, z, sq, vbx, vby, vbz);
+            bool in1 = window(pxs + xx + 1, pys + yy, z, sq, vbx, vby, vbz);
 #endif
+            in0 = in0 && c0 + 2 * lane < ppe;
+            in1 = in1 && c0 + 2 * lane < ppe && xx + 1 < pbx;
             const int pk0 = (ox + xx) | ((oy + yy) << 10) | ((z - B.zs) << 20);
-            const int pk1 = (ox + xx1) | ((oy + yy1) << 10) | ((z - B.zs) << 20);
-            xx = xx1 + r64;
-            yy = yy1 + q64;
-            if (xx >= pbx) {
-                xx -= pbx;
+            const int pk1 = pk0 + 1;
+            xx += r128;
+            yy += q128;
+            if (xx >= pbe) {
+                xx -= pbe;
                 yy++;
             }
             const unsigned long long m0 = __ballot(in0), m1 = __ballot(in1);
             if ((m0 | m1) == 0ull)
                 continue;
-            const uint32_t n0 = (uint32_t)__popcll(m0);
+            // queue position = the number of accepted voxels at lower positions: both voxels of every lower lane,
+            // and this lane's first for its second
+            const uint32_t before = (uint32_t)__popcll(m0 & lt_mask) + (uint32_t)__popcll(m1 & lt_mask);
             if (in0)
-                queue[(qtail + (uint32_t)__popcll(m0 & lt_mask)) & (DQ - 1)] = pk0;
+                queue[(qtail + before) & (DQ - 1)] = pk0;
             if (in1)
-                queue[(qtail + n0 + (uint32_t)__popcll(m1 & lt_mask)) & (DQ - 1)] = pk1;
-            qtail += n0 + (uint32_t)__popcll(m1);
+                queue[(qtail + before + (in0 ? 1u : 0u)) & (DQ - 1)] = pk1;
+            qtail += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
             wave_sync();
             // A full batch leaves the queue as soon as its samples are requested (its packed
             // coordinates travel in ppk), one batch ahead of its binning and commit
