@@ -375,6 +375,17 @@ __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
     // extended-z plane r (local index; outside the slab at the global faces): one or two requests
     auto ext_z = [&](int r, bool stores) -> float4 {
         const int i = r + off;
+        // Every plane but the high face's virtual ones (block-uniform) takes ONE request and nothing else: as a
+        // path of its own it frees the plane loop of the selects and copies that merged it with the two-request
+        // case (~65 of ~340 vector instructions per plane at 13 taps, and the wide instances are bound by their
+        // vector instructions): the 13-tap launch in the step 0.44-0.45 -> 0.39-0.41 ms, the pyramid alone 3.55-3.59
+        // -> 3.48-3.54 ms, bit-identical.  (Not at 17 taps: there the second path costs the register allocator
+        // 72 dwords of scratch.)
+        if (HW < 8 && i < endz) {
+            const float4 yv = yfilt();
+            shist = ((shist << 1) | (int)(stores && wave_stores)) & 7;
+            return yv;
+        }
         int np = 1;
         float w0 = 1.0f, w1 = 0.0f;
         if (i >= endz) {
