@@ -398,20 +398,21 @@ __global__ __launch_bounds__(16 * TY) __attribute__((amdgpu_waves_per_eu(4, 4)))
                     w1 = Ez.w1[mm];
                 }
         }
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
         for (int k = 0; k < np; k++) {
             const float4 yv = yfilt();
             // (the store that follows this plane belongs to the LAST of its requests)
             shist = ((shist << 1) | (int)(stores && wave_stores && k + 1 == np)) & 7;
+            // (block-uniform; the second request of a virtual plane interpolates in place: w0 * first + w1 * second)
             if (k == 0)
                 a = yv;
             else
-                b = yv;
+                a = Vec<4>::lerp(w0, a, w1, yv);
         }
         if (np == 0)
             shist = ((shist << 1) | (int)(stores && wave_stores)) & 7;   // (a store without a request)
-        return np == 2 ? Vec<4>::lerp(w0, a, w1, b) : a;
+        return a;
     };
 
     float4 ring[W];
