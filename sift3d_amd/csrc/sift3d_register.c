@@ -246,6 +246,17 @@ static int reg_solve4(double M[4][4], double R[3][4], double A[3][4])
 }
 
 /* least-squares affine dst = A [src; 1] over the points selected by idx */
+/* threads of the RANSAC scoring loop: one per four iterations, at most 16 */
+static int reg_threads(int iters)
+{
+    int t = omp_get_num_procs();
+    if (t > 16)
+        t = 16;
+    if (t > (iters + 3) / 4)
+        t = (iters + 3) / 4;
+    return t < 1 ? 1 : t;
+}
+
 static int reg_fit(const double *src, const double *dst, const int *idx, int m, double A[3][4])
 {
     double M[4][4], R[3][4];
@@ -313,7 +324,9 @@ int sift3d_amd_ransac_affine(const double *src, const double *dst, int n, double
                 } while (dup);
             }
         }
-#pragma omp parallel for schedule(dynamic, 4)
+        /* (an explicit team: libgomp's default is one thread per CPU it SEES, 256 on a GPU box whose quota is 16
+         * cores -- hundreds of spinning threads for 500 short iterations) */
+#pragma omp parallel for schedule(dynamic, 4) num_threads(reg_threads(num_iter))
         for (it = 0; it < num_iter; it++) {
             double M[3][4];
             int cnt = 0, j, k;

@@ -20,8 +20,16 @@
 #include <math.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <omp.h>
 
 #include "synth.h"
+
+/* (an explicit team: libgomp's default is one thread per CPU it sees -- 256 on a GPU box whose quota is 16 cores) */
+static int synth_threads(void)
+{
+    const int t = omp_get_num_procs();
+    return t > 16 ? 16 : t < 1 ? 1 : t;
+}
 
 static inline uint64_t xs64(uint64_t *s)
 {
@@ -136,7 +144,7 @@ float sift3d_amd_synth_lattice_voxel(int x, int y, int z, uint64_t seed)
 void sift3d_amd_synth_lattice(float *vol, int nx, int ny, int nz, uint64_t seed)
 {
     int z;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(synth_threads())
     for (z = 0; z < nz; z++) {
         int x, y;
         for (y = 0; y < ny; y++)
